@@ -1,0 +1,144 @@
+/*
+ * drrt_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU parity oracle for the eikonal ray-march hot path: a plain-C restatement of
+ *   /root/reference/src/tracer.cpp, src/volume.cpp, src/cylinder_volume.cpp
+ * (line citations inside drrt_oracle_impl.h).  Built as oracle/_build/libdrrt_oracle.so
+ * by oracle/Makefile; loaded through ctypes by oracle/oracle.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library -- as the checker / reported baseline, never as the product path.
+ *
+ * Parity status: "parity unpinned" against the reference's native enoki build (enoki is
+ * an empty, un-vendored submodule; the reference ships no tests or golden vectors).
+ * What is pinned: see tests/golden/README.md.
+ *
+ * Compile with -ffp-contract=off so that the only fused multiply-adds are the ones the
+ * reference writes explicitly (fmadd / lerp).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stddef.h>
+
+/* ---- float instantiation ---------------------------------------------------------- */
+#define REAL float
+#define FN(name) name##_f32
+#define FLOOR floorf
+#define SQRT sqrtf
+#define FMA fmaf
+#include "drrt_oracle_impl.h"
+#undef REAL
+#undef FN
+#undef FLOOR
+#undef SQRT
+#undef FMA
+#undef CYL_EPS
+
+/* ---- double instantiation --------------------------------------------------------- */
+#define REAL double
+#define FN(name) name##_f64
+#define FLOOR floor
+#define SQRT sqrt
+#define FMA fma
+#include "drrt_oracle_impl.h"
+#undef REAL
+#undef FN
+#undef FLOOR
+#undef SQRT
+#undef FMA
+#undef CYL_EPS
+
+#define EXPORT __attribute__((visibility("default")))
+
+#define DEFINE_API(REAL, SFX)                                                                  \
+EXPORT int oracle_trace_##SFX(const REAL* rif, const int* res, long long nvox, size_t n,       \
+    const REAL* pos, const REAL* vel, REAL h, REAL ds, REAL* xt, REAL* vt,                     \
+    int* steps_out, long long* n_failed, int* iters) {                                         \
+  return trace_generic_##SFX(0, rif, NULL, res, nvox, n, pos, vel, NULL, NULL, h, ds, xt, vt,  \
+                             NULL, steps_out, n_failed, iters);                                \
+}                                                                                              \
+EXPORT int oracle_trace_pln_##SFX(const REAL* rif, const int* res, long long nvox, size_t n,   \
+    const REAL* pos, const REAL* vel, const REAL* pln_o, const REAL* pln_d, REAL h, REAL ds,   \
+    REAL* xt, REAL* vt, unsigned char* failmask, int* steps_out, long long* n_failed,          \
+    int* iters) {                                                                              \
+  return trace_generic_##SFX(1, rif, NULL, res, nvox, n, pos, vel, pln_o, pln_d, h, ds, xt, vt,\
+                             failmask, steps_out, n_failed, iters);                            \
+}                                                                                              \
+EXPORT int oracle_trace_sdf_##SFX(const REAL* rif, const REAL* sdf, const int* res,            \
+    long long nvox, size_t n, const REAL* pos, const REAL* vel, REAL h, REAL ds,               \
+    REAL* xt, REAL* vt, int* steps_out, long long* n_failed, int* iters) {                     \
+  return trace_generic_##SFX(2, rif, sdf, res, nvox, n, pos, vel, NULL, NULL, h, ds, xt, vt,   \
+                             NULL, steps_out, n_failed, iters);                                \
+}                                                                                              \
+EXPORT int oracle_trace_target_##SFX(const REAL* rif, const int* res, long long nvox, size_t n,\
+    const REAL* pos, const REAL* vel, const REAL* target, REAL h, REAL ds,                     \
+    REAL* xt, REAL* vt, REAL* dist2, long long* n_failed, int* iters) {                        \
+  return trace_target_impl_##SFX(rif, res, nvox, n, pos, vel, target, h, ds, xt, vt, dist2,    \
+                                 n_failed, iters);                                             \
+}                                                                                              \
+EXPORT int oracle_trace_cable_##SFX(const REAL* rif, size_t rres, REAL radius, REAL length,    \
+    size_t n, const REAL* pos, const REAL* vel, const REAL* target, REAL ds,                   \
+    REAL* xt, REAL* vt, REAL* dist2, long long* n_failed, long long* steps_total) {            \
+  return trace_cable_impl_##SFX(rif, rres, radius, length, n, pos, vel, target, ds, xt, vt,    \
+                                dist2, n_failed, steps_total);                                 \
+}                                                                                              \
+EXPORT int oracle_backtrace_##SFX(const REAL* rif, const int* res, long long nvox, size_t n,   \
+    const REAL* xt, const REAL* vt, const REAL* dx, const REAL* dv, REAL h, REAL ds,           \
+    REAL grad_scale, REAL* grad, long long* steps_total) {                                     \
+  return backtrace_generic_##SFX(0, rif, NULL, res, nvox, n, xt, vt, dx, dv, h, ds,            \
+                                 grad_scale, grad, steps_total);                               \
+}                                                                                              \
+EXPORT int oracle_backtrace_sdf_##SFX(const REAL* rif, const REAL* sdf, const int* res,        \
+    long long nvox, size_t n, const REAL* xt, const REAL* vt, const REAL* dx, const REAL* dv,  \
+    REAL h, REAL ds, REAL grad_scale, REAL* grad, long long* steps_total) {                    \
+  return backtrace_generic_##SFX(1, rif, sdf, res, nvox, n, xt, vt, dx, dv, h, ds,             \
+                                 grad_scale, grad, steps_total);                               \
+}                                                                                              \
+EXPORT int oracle_backtrace_cable_##SFX(const REAL* rif, size_t rres, REAL radius, REAL length,\
+    size_t n, const REAL* xt, const REAL* vt, const REAL* dx, const REAL* dv, REAL ds,         \
+    REAL* grad, long long* steps_total) {                                                      \
+  return backtrace_cable_impl_##SFX(rif, rres, radius, length, n, xt, vt, dx, dv, ds, grad,    \
+                                    steps_total);                                              \
+}                                                                                              \
+/* point-wise samplers, for pinning against core/grid.py / core/cable.py */                    \
+EXPORT int oracle_eval_grad_##SFX(const REAL* data, const int* res, REAL h, size_t n,          \
+    const REAL* pts, const unsigned char* mask, REAL* out_n, REAL* out_g) {                    \
+  for (size_t i = 0; i < n; ++i)                                                               \
+    vol_eval_grad_##SFX(data, res, h, pts + 3*i, mask ? mask[i] : 1, out_n + i, out_g + 3*i);  \
+  return 0;                                                                                    \
+}                                                                                              \
+EXPORT int oracle_eval_hess_##SFX(const REAL* data, const int* res, REAL h, size_t n,          \
+    const REAL* pts, const unsigned char* mask, REAL* out_h /* (n,3): xy,xz,yz */) {           \
+  for (size_t i = 0; i < n; ++i)                                                               \
+    vol_eval_hess_##SFX(data, res, h, pts + 3*i, mask ? mask[i] : 1, out_h + 3*i);             \
+  return 0;                                                                                    \
+}                                                                                              \
+EXPORT int oracle_splat_##SFX(REAL* data, const int* res, REAL h, size_t n, const REAL* pts,   \
+    const REAL* val, const REAL* grad, const unsigned char* mask, REAL grad_scale) {           \
+  for (size_t i = 0; i < n; ++i)                                                               \
+    vol_splat_##SFX(data, res, h, pts + 3*i, val[i], grad + 3*i, mask ? mask[i] : 1,           \
+                    grad_scale);                                                               \
+  return 0;                                                                                    \
+}                                                                                              \
+EXPORT int oracle_cyl_eval_grad_##SFX(const REAL* data, size_t rres, REAL radius, size_t n,    \
+    const REAL* pts, REAL* out_n, REAL* out_g) {                                               \
+  for (size_t i = 0; i < n; ++i)                                                               \
+    cyl_eval_grad_##SFX(data, rres, radius, pts + 3*i, out_n + i, out_g + 3*i);                \
+  return 0;                                                                                    \
+}                                                                                              \
+EXPORT int oracle_cyl_eval_hess_##SFX(const REAL* data, size_t rres, REAL radius, size_t n,    \
+    const REAL* pts, REAL* out_h /* (n,4): H00,H02,H20,H22 */) {                               \
+  for (size_t i = 0; i < n; ++i)                                                               \
+    cyl_eval_hess_##SFX(data, rres, radius, pts + 3*i, out_h + 4*i);                           \
+  return 0;                                                                                    \
+}                                                                                              \
+EXPORT int oracle_cyl_splat_##SFX(REAL* data, size_t rres, REAL radius, size_t n,              \
+    const REAL* pts, const REAL* val, const REAL* grad, const unsigned char* mask) {           \
+  for (size_t i = 0; i < n; ++i)                                                               \
+    cyl_splat_##SFX(data, rres, radius, pts + 3*i, val[i], grad + 3*i, mask ? mask[i] : 1);    \
+  return 0;                                                                                    \
+}
+
+DEFINE_API(float, f32)
+DEFINE_API(double, f64)
