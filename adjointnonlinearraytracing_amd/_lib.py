@@ -1,0 +1,82 @@
+"""ctypes binding of ``libdrrt_hip.so`` -- the C ABI declared in ``include/drrt_hip.h``.
+
+There is NO fallback: if the shared library is missing or a call fails, a ``RuntimeError`` is
+raised (the reference turns ``std::runtime_error`` into Python ``RuntimeError`` the same way,
+pybind default translator, ``/root/reference/src/volume.cpp:28,37,115,124``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdrrt_hip.so")
+
+# flags (include/drrt_hip.h)
+FLAG_NONE = 0
+FLAG_SORT_RAYS = 1
+FLAG_CORRECTED_H = 2
+FLAG_NO_ZERO = 4
+FLAG_DIRECT_ATOMICS = 8
+
+ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
+
+
+class Stats(C.Structure):
+    """Mirror of ``drrt_stats`` (device-resident; copy back to read)."""
+    _fields_ = [("ray_steps", C.c_ulonglong), ("n_failed", C.c_ulonglong),
+                ("iters", C.c_uint), ("reserved", C.c_uint)]
+
+
+STATS_BYTES = C.sizeof(Stats)
+
+_vp, _f, _sz, _u, _ll, _i = C.c_void_p, C.c_float, C.c_size_t, C.c_uint, C.c_longlong, C.c_int
+_tail = [_vp, _vp, _sz, _u, _vp]          # stats, workspace, workspace_bytes, flags, stream
+
+SIGNATURES = {
+    # name: (restype, argtypes)   -- must stay in sync with include/drrt_hip.h
+    "drrt_workspace_bytes": (_sz, [_sz, _u]),
+    "drrt_last_error": (C.c_char_p, []),
+    "drrt_version": (C.c_char_p, []),
+    "drrt_trace_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),
+    "drrt_trace_pln_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp] + _tail),
+    "drrt_trace_target_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp] + _tail),
+    "drrt_trace_sdf_f32": (_i, [_vp, _vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),
+    "drrt_trace_cable_f32": (_i, [_vp, _sz, _f, _f, _sz, _vp, _vp, _vp, _f, _vp, _vp, _vp] + _tail),
+    "drrt_backtrace_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
+    "drrt_backtrace_sdf_f32": (_i, [_vp, _vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
+    "drrt_backtrace_cable_f32": (_i, [_vp, _sz, _f, _f, _sz, _vp, _vp, _vp, _vp, _f, _vp] + _tail),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libdrrt_hip.so (after torch, so that both share ONE HIP runtime in the process)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libdrrt_hip.so not found at {LIB_PATH}: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C adjointnonlinearraytracing_amd/csrc`.  There is no CPU fallback.")
+    import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours binds to the same SONAME)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch: loud
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().drrt_last_error().decode()
+
+
+def check(rc: int) -> None:
+    """Negative status -> RuntimeError carrying the library's message (reference: pybind maps
+    std::runtime_error to RuntimeError)."""
+    if rc != 0:
+        raise RuntimeError(last_error() or f"drrt_hip error {rc}")

@@ -1,0 +1,306 @@
+"""`drrt` module mirror: ``TracerC`` / ``TracerS`` objects with the reference's method names and
+argument order (``/root/reference/src/drrt.cpp:21-59``, ``include/tracer.h:15-89``), operating on
+torch tensors instead of enoki arrays and backed by the hand-written HIP kernels in
+``csrc/`` through the C ABI (``include/drrt_hip.h``).
+
+* ``TracerC`` -- tensors on the ``cuda`` (ROCm) device; asynchronous on torch's current stream.
+* ``TracerS`` -- the reference's CPU class (``Tracer<false,false>``, binds trace / trace_sdf /
+  trace_target / backtrace only, ``src/drrt.cpp:38-45``).  Here it accepts CPU tensors, stages
+  them to the GPU, runs the SAME HIP kernels and copies the results back: there is deliberately
+  no CPU compute path in this package.
+* ``TracerD`` (enoki autodiff, ``src/drrt.cpp:28-36``) is out of scope; constructing it raises.
+
+All methods ``detach()`` / ``contiguous()`` / cast to fp32 exactly where the reference narrows
+(``core/tracer.py:299-301``, ``include/tracer.h:20-21``); ``res`` may be any 3-sequence
+(``torch.Size`` is what the scripts pass, ``core/tracer.py:298,307``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class Options:
+    sort_rays: bool = True        # locality-sort rays by entry voxel (DRRT_FLAG_SORT_RAYS)
+    corrected_h: bool = False     # adjoint: divide gradient splat by h; default = as written
+    check_failed: bool = True     # sync + print "failed to exit all rays" like src/tracer.cpp:89-90
+    direct_atomics: bool = False  # adjoint: one global atomic per tap (debug / A-B)
+
+
+options = Options()
+
+# last call's statistics (ray_steps, n_failed, iters) as a device tensor of 3 int64 words
+last_stats: Optional[torch.Tensor] = None
+
+_workspaces: Dict[torch.device, torch.Tensor] = {}
+
+
+def _flags(adjoint: bool = False) -> int:
+    f = 0
+    if options.sort_rays:
+        f |= _lib.FLAG_SORT_RAYS
+    if adjoint and options.corrected_h:
+        f |= _lib.FLAG_CORRECTED_H
+    if adjoint and options.direct_atomics:
+        f |= _lib.FLAG_DIRECT_ATOMICS
+    return f
+
+
+def _workspace(n: int, flags: int, device: torch.device) -> torch.Tensor:
+    need = int(_lib.load().drrt_workspace_bytes(n, flags))
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def _dev(t: torch.Tensor) -> torch.device:
+    if not t.is_cuda:
+        raise RuntimeError("TracerC expects tensors on the cuda (ROCm) device; use TracerS for host tensors")
+    return t.device
+
+
+def _f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _rays(t: torch.Tensor, device: torch.device, n: Optional[int] = None) -> torch.Tensor:
+    t = _f32(t, device)
+    if t.dim() != 2 or t.shape[1] != 3 or (n is not None and t.shape[0] != n):
+        raise RuntimeError(f"expected a ({'N' if n is None else n},3) ray tensor, got {tuple(t.shape)}")
+    return t
+
+
+def _res3(res: Sequence[int]):
+    r = [int(v) for v in res]
+    if len(r) != 3:
+        raise RuntimeError("res must have 3 entries")
+    return (C.c_int * 3)(*r)
+
+
+def _stream(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _new_stats(device: torch.device) -> torch.Tensor:
+    global last_stats
+    last_stats = torch.empty(3, dtype=torch.int64, device=device)
+    return last_stats
+
+
+def read_stats(stats: Optional[torch.Tensor] = None) -> Dict[str, int]:
+    """Synchronising read of a stats block -> dict(ray_steps, n_failed, iters)."""
+    s = (last_stats if stats is None else stats).cpu()
+    return dict(ray_steps=int(s[0]), n_failed=int(s[1]), iters=int(s[2]) & 0xFFFFFFFF)
+
+
+def _warn_failed(stats: torch.Tensor) -> None:
+    if options.check_failed and int(stats[1].item()) > 0:
+        print("failed to exit all rays")            # src/tracer.cpp:90
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class TracerC:
+    """GPU tracer without autodiff -- mirror of ``drrt.TracerC`` (``src/drrt.cpp:47-58``)."""
+
+    # ---- forward ------------------------------------------------------------------------
+    def trace(self, rif, res, pos, vel, h, ds) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Tracer::trace, src/tracer.cpp:35-100."""
+        dev = _dev(rif)
+        with torch.cuda.device(dev):
+            rif_, pos_ = _f32(rif, dev).reshape(-1), _rays(pos, dev)
+            n = pos_.shape[0]
+            vel_ = _rays(vel, dev, n)
+            xt, vt = torch.empty_like(pos_), torch.empty_like(vel_)
+            fl = _flags()
+            ws, st = _workspace(n, fl, dev), _new_stats(dev)
+            _lib.check(_lib.load().drrt_trace_f32(
+                _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), float(h), float(ds),
+                _p(xt), _p(vt), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+            _warn_failed(st)
+        return xt, vt
+
+    def trace_pln(self, rif, res, pos, vel, pln_o, pln_d, h, ds):
+        """Tracer::trace_plane, src/tracer.cpp:102-172 -> (xt, vt, failmask uint8)."""
+        dev = _dev(rif)
+        with torch.cuda.device(dev):
+            rif_, pos_ = _f32(rif, dev).reshape(-1), _rays(pos, dev)
+            n = pos_.shape[0]
+            vel_, po, pd = _rays(vel, dev, n), _rays(pln_o, dev, n), _rays(pln_d, dev, n)
+            xt, vt = torch.empty_like(pos_), torch.empty_like(vel_)
+            fm = torch.empty(n, dtype=torch.uint8, device=dev)
+            fl = _flags()
+            ws, st = _workspace(n, fl, dev), _new_stats(dev)
+            _lib.check(_lib.load().drrt_trace_pln_f32(
+                _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), _p(po), _p(pd),
+                float(h), float(ds), _p(xt), _p(vt), _p(fm), _p(st), _p(ws), ws.numel(), fl,
+                _stream(dev)))
+            _warn_failed(st)
+        return xt, vt, fm
+
+    def trace_target(self, rif, res, pos, vel, target, h, ds):
+        """Tracer::trace_target, src/tracer.cpp:174-242 -> (xt, vt, dist2)."""
+        dev = _dev(rif)
+        with torch.cuda.device(dev):
+            rif_, pos_ = _f32(rif, dev).reshape(-1), _rays(pos, dev)
+            n = pos_.shape[0]
+            vel_, tg = _rays(vel, dev, n), _rays(target, dev, n)
+            xt, vt = torch.empty_like(pos_), torch.empty_like(vel_)
+            d2 = torch.empty(n, dtype=torch.float32, device=dev)
+            fl = _flags()
+            ws, st = _workspace(n, fl, dev), _new_stats(dev)
+            _lib.check(_lib.load().drrt_trace_target_f32(
+                _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), _p(tg),
+                float(h), float(ds), _p(xt), _p(vt), _p(d2), _p(st), _p(ws), ws.numel(), fl,
+                _stream(dev)))
+            _warn_failed(st)
+        return xt, vt, d2
+
+    def trace_sdf(self, rif, sdf, res, pos, vel, h, ds):
+        """Tracer::trace_sdf, src/tracer.cpp:244-310."""
+        dev = _dev(rif)
+        with torch.cuda.device(dev):
+            rif_, sdf_ = _f32(rif, dev).reshape(-1), _f32(sdf, dev).reshape(-1)
+            if sdf_.numel() != rif_.numel():
+                raise RuntimeError("Resolution doesn't match data")      # src/volume.cpp:37
+            pos_ = _rays(pos, dev)
+            n = pos_.shape[0]
+            vel_ = _rays(vel, dev, n)
+            xt, vt = torch.empty_like(pos_), torch.empty_like(vel_)
+            fl = _flags()
+            ws, st = _workspace(n, fl, dev), _new_stats(dev)
+            _lib.check(_lib.load().drrt_trace_sdf_f32(
+                _p(rif_), _p(sdf_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_),
+                float(h), float(ds), _p(xt), _p(vt), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+        return xt, vt
+
+    def trace_cable(self, rif, radius, length, pos, vel, target, ds):
+        """Tracer::trace_cable, src/tracer.cpp:312-382 -> (xt, vt, dist2)."""
+        dev = _dev(rif)
+        with torch.cuda.device(dev):
+            rif_, pos_ = _f32(rif, dev).reshape(-1), _rays(pos, dev)
+            n = pos_.shape[0]
+            vel_, tg = _rays(vel, dev, n), _rays(target, dev, n)
+            xt, vt = torch.empty_like(pos_), torch.empty_like(vel_)
+            d2 = torch.empty(n, dtype=torch.float32, device=dev)
+            ws, st = _workspace(n, 0, dev), _new_stats(dev)
+            _lib.check(_lib.load().drrt_trace_cable_f32(
+                _p(rif_), rif_.numel(), float(radius), float(length), n, _p(pos_), _p(vel_), _p(tg),
+                float(ds), _p(xt), _p(vt), _p(d2), _p(st), _p(ws), ws.numel(), 0, _stream(dev)))
+            _warn_failed(st)
+        return xt, vt, d2
+
+    # ---- adjoint ------------------------------------------------------------------------
+    def backtrace(self, rif, res, xt, vt, dx, dv, h, ds) -> torch.Tensor:
+        """Tracer::backtrace, src/tracer.cpp:384-440 -> flat dL/dn (fp32[nvox])."""
+        dev = _dev(rif)
+        with torch.cuda.device(dev):
+            rif_, xt_ = _f32(rif, dev).reshape(-1), _rays(xt, dev)
+            n = xt_.shape[0]
+            vt_, dx_, dv_ = _rays(vt, dev, n), _rays(dx, dev, n), _rays(dv, dev, n)
+            grad = torch.empty_like(rif_)
+            fl = _flags(adjoint=True)
+            ws, st = _workspace(n, fl, dev), _new_stats(dev)
+            _lib.check(_lib.load().drrt_backtrace_f32(
+                _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
+                float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+        return grad
+
+    def backtrace_sdf(self, rif, sdf, res, xt, vt, dx, dv, h, ds) -> torch.Tensor:
+        """Tracer::backtrace_sdf, src/tracer.cpp:443-509."""
+        dev = _dev(rif)
+        with torch.cuda.device(dev):
+            rif_, sdf_ = _f32(rif, dev).reshape(-1), _f32(sdf, dev).reshape(-1)
+            if sdf_.numel() != rif_.numel():
+                raise RuntimeError("Resolution doesn't match data")
+            xt_ = _rays(xt, dev)
+            n = xt_.shape[0]
+            vt_, dx_, dv_ = _rays(vt, dev, n), _rays(dx, dev, n), _rays(dv, dev, n)
+            grad = torch.empty_like(rif_)
+            fl = _flags(adjoint=True)
+            ws, st = _workspace(n, fl, dev), _new_stats(dev)
+            _lib.check(_lib.load().drrt_backtrace_sdf_f32(
+                _p(rif_), _p(sdf_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
+                float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+        return grad
+
+    def backtrace_cable(self, rif, radius, length, xt, vt, dx, dv, ds) -> torch.Tensor:
+        """Tracer::backtrace_cable, src/tracer.cpp:511-567 -> dL/d(profile) fp32[rres]."""
+        dev = _dev(rif)
+        with torch.cuda.device(dev):
+            rif_, xt_ = _f32(rif, dev).reshape(-1), _rays(xt, dev)
+            n = xt_.shape[0]
+            vt_, dx_, dv_ = _rays(vt, dev, n), _rays(dx, dev, n), _rays(dv, dev, n)
+            grad = torch.empty_like(rif_)
+            ws, st = _workspace(n, 0, dev), _new_stats(dev)
+            _lib.check(_lib.load().drrt_backtrace_cable_f32(
+                _p(rif_), rif_.numel(), float(radius), float(length), n, _p(xt_), _p(vt_), _p(dx_),
+                _p(dv_), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), 0, _stream(dev)))
+        return grad
+
+    # ---- print-only smoke methods of the reference (src/tracer.cpp:16-33) ------------------
+    def test(self) -> torch.Tensor:
+        """Tracer::tester: returns a zero 3-vector."""
+        return torch.zeros(1, 3)
+
+    def testscale(self, p) -> None:
+        """Tracer::test_in: prints 1.1+0.5 and its floor2int (print-only in the reference)."""
+        one = torch.full((1, 3), 1.1) + 0.5
+        print(one)
+        print(torch.floor(one).to(torch.int32))
+
+
+class TracerS:
+    """Host-tensor tracer -- mirror of ``drrt.TracerS`` (``src/drrt.cpp:38-45``): binds only
+    ``trace``, ``trace_sdf``, ``trace_target``, ``backtrace``.  Inputs may live on
+    the CPU; compute happens on ``cuda:0`` through ``TracerC`` and results return to the
+    inputs' device.  No CPU compute path exists in this package."""
+
+    def __init__(self, device: str = "cuda:0"):
+        self._dev = torch.device(device)
+        self._c = TracerC()
+
+    def _up(self, *ts):
+        return [t.to(self._dev) if isinstance(t, torch.Tensor) else t for t in ts]
+
+    def trace(self, rif, res, pos, vel, h, ds):
+        out_dev = pos.device
+        r, p, v = self._up(rif, pos, vel)
+        return tuple(t.to(out_dev) for t in self._c.trace(r, res, p, v, h, ds))
+
+    def trace_sdf(self, rif, sdf, res, pos, vel, h, ds):
+        out_dev = pos.device
+        r, s, p, v = self._up(rif, sdf, pos, vel)
+        return tuple(t.to(out_dev) for t in self._c.trace_sdf(r, s, res, p, v, h, ds))
+
+    def trace_target(self, rif, res, pos, vel, target, h, ds):
+        out_dev = pos.device
+        r, p, v, tg = self._up(rif, pos, vel, target)
+        return tuple(t.to(out_dev) for t in self._c.trace_target(r, res, p, v, tg, h, ds))
+
+    def backtrace(self, rif, res, xt, vt, dx, dv, h, ds):
+        out_dev = rif.device
+        r, a, b, c, d = self._up(rif, xt, vt, dx, dv)
+        return self._c.backtrace(r, res, a, b, c, d, h, ds).to(out_dev)
+
+    test = TracerC.test
+    testscale = TracerC.testscale
+
+
+class TracerD:
+    """enoki-autodiff tracer of the reference (``src/drrt.cpp:28-36``): not provided -- the
+    hand-written adjoint (``TracerC.backtrace*``) is the supported gradient path."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError(
+            "drrt.TracerD (enoki autodiff) is out of scope; use TracerC + tracer.BackTracerC")

@@ -1,0 +1,129 @@
+"""Counterpart of the reference's ``core/tracer.py``: the ``torch.autograd.Function`` classes the
+``*_opt.py`` scripts call, with identical names, argument order and return arity
+(``/root/reference/core/tracer.py:294-526``), backed by ``drrt.TracerC`` (HIP kernels).
+
+Contract reproduced from the reference:
+  * forward inputs are detached, flattened C-order and narrowed to fp32 (``:299-301``);
+  * forward stores ``rif``, the exit rays and the scalars on ``ctx`` and returns fresh tensors;
+  * backward returns ``drif`` reshaped to ``rif.shape`` and ``None`` for every other input
+    (no gradient w.r.t. ``x``, ``v``: ``:335,386,432,479,526``);
+  * ``BackPlaneTracerC`` / ``BackTargetTracerC`` backward run the GENERIC ``backtrace`` from the
+    recorded state (``:376,422``); ``BackPlaneTracerC.backward`` zeroes ``grad_x`` on
+    rays whose ``outmask`` gradient is set, as written (``:366-367``).
+The enoki pool trim (``enoki.cuda_malloc_trim()``, ``:314``) has no counterpart: outputs are
+torch allocations.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import drrt
+
+
+class BackTracerC(torch.autograd.Function):
+    """core/tracer.py:294-335 -- ``apply(rif, x, v, h, ds) -> (xt, vt)``."""
+
+    @staticmethod
+    def forward(ctx, rif, x, v, h, ds):
+        ctx.shape = rif.shape
+        ctx.rif = rif.detach().flatten()
+        ctx.h, ctx.ds = h, ds
+        ctx.outx, ctx.outv = drrt.TracerC().trace(ctx.rif, ctx.shape, x.detach(), v.detach(), h, ds)
+        return ctx.outx.clone(), ctx.outv.clone()
+
+    @staticmethod
+    def backward(ctx, grad_x, grad_v):
+        drif = drrt.TracerC().backtrace(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v,
+                                        ctx.h, ctx.ds).reshape(*ctx.shape)
+        return drif, None, None, None, None
+
+
+class BackPlaneTracerC(torch.autograd.Function):
+    """core/tracer.py:338-386 -- ``apply(rif, x, v, sp, sn, h, ds) -> (xt, vt, failmask bool)``."""
+
+    @staticmethod
+    def forward(ctx, rif, x, v, sp, sn, h, ds):
+        ctx.shape = rif.shape
+        ctx.rif = rif.detach().flatten()
+        ctx.h, ctx.ds = h, ds
+        ctx.outx, ctx.outv, outmask = drrt.TracerC().trace_pln(
+            ctx.rif, ctx.shape, x.detach(), v.detach(), sp.detach(), sn.detach(), h, ds)
+        outmask = outmask.to(torch.bool)
+        ctx.mark_non_differentiable(outmask)
+        return ctx.outx.clone(), ctx.outv.clone(), outmask
+
+    @staticmethod
+    def backward(ctx, grad_x, grad_v, outmask):
+        if outmask is not None and outmask.dtype == torch.bool:     # as written, :366-367
+            grad_x = grad_x.clone()
+            grad_x[outmask] = 0
+        drif = drrt.TracerC().backtrace(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v,
+                                        ctx.h, ctx.ds).reshape(*ctx.shape)
+        return drif, None, None, None, None, None, None
+
+
+class BackTargetTracerC(torch.autograd.Function):
+    """core/tracer.py:389-432 -- ``apply(rif, x, v, sp, h, ds) -> (xt, vt, dist2)``."""
+
+    @staticmethod
+    def forward(ctx, rif, x, v, sp, h, ds):
+        ctx.shape = rif.shape
+        ctx.rif = rif.detach().flatten()
+        ctx.h, ctx.ds = h, ds
+        ctx.outx, ctx.outv, dist2 = drrt.TracerC().trace_target(
+            ctx.rif, ctx.shape, x.detach(), v.detach(), sp.detach(), h, ds)
+        return ctx.outx.clone(), ctx.outv.clone(), dist2
+
+    @staticmethod
+    def backward(ctx, grad_x, grad_v, outdist):
+        drif = drrt.TracerC().backtrace(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v,
+                                        ctx.h, ctx.ds).reshape(*ctx.shape)
+        return drif, None, None, None, None, None
+
+
+class BackSDFTracerC(torch.autograd.Function):
+    """core/tracer.py:435-479 -- ``apply(rif, sdf, x, v, h, ds) -> (xt, vt)``."""
+
+    @staticmethod
+    def forward(ctx, rif, sdf, x, v, h, ds):
+        ctx.shape = rif.shape
+        ctx.rif = rif.detach().flatten()
+        ctx.sdf = sdf.detach().flatten()
+        ctx.h, ctx.ds = h, ds
+        ctx.outx, ctx.outv = drrt.TracerC().trace_sdf(ctx.rif, ctx.sdf, ctx.shape, x.detach(),
+                                                      v.detach(), h, ds)
+        return ctx.outx.clone(), ctx.outv.clone()
+
+    @staticmethod
+    def backward(ctx, grad_x, grad_v):
+        drif = drrt.TracerC().backtrace_sdf(ctx.rif, ctx.sdf, ctx.shape, ctx.outx, ctx.outv,
+                                            grad_x, grad_v, ctx.h, ctx.ds).reshape(*ctx.shape)
+        return drif, None, None, None, None, None
+
+
+class BackCableTracerC(torch.autograd.Function):
+    """core/tracer.py:482-526 -- ``apply(rif (Rr,), radius, length, x, v, sp, ds) -> (xt, vt, dist2)``."""
+
+    @staticmethod
+    def forward(ctx, rif, radius, length, x, v, sp, ds):
+        ctx.radius, ctx.length, ctx.ds = radius, length, ds
+        ctx.rif = rif.detach().flatten()
+        ctx.outx, ctx.outv, dist2 = drrt.TracerC().trace_cable(
+            ctx.rif, radius, length, x.detach(), v.detach(), sp.detach(), ds)
+        return ctx.outx.clone(), ctx.outv.clone(), dist2
+
+    @staticmethod
+    def backward(ctx, grad_x, grad_v, outdist):
+        drif = drrt.TracerC().backtrace_cable(ctx.rif, ctx.radius, ctx.length, ctx.outx, ctx.outv,
+                                              grad_x, grad_v, ctx.ds)
+        return drif, None, None, None, None, None, None
+
+
+# The enoki-autodiff classes of the reference (core/tracer.py:16-291) are out of scope (two of
+# them are broken upstream).  Scripts select them with `autodiff=True`
+# (core/luneburg_opt.py:80-83); the names resolve to the adjoint classes so that flag keeps
+# working, with the documented difference that no gradient flows to x, v.
+ADTracerC = BackTracerC
+ADPlaneTracerC = BackPlaneTracerC
+ADSDFTracerC = BackSDFTracerC
+ADCableTracerC = BackCableTracerC

@@ -1,0 +1,148 @@
+/*
+ * drrt_hip.h -- C ABI of the MI355X-native eikonal ray-march library (libdrrt_hip.so).
+ *
+ * Drop-in boundary for the hot path of ArjunTeh/AdjointNonlinearRayTracing: one entry
+ * point per method of the reference's `drrt.TracerC` pybind class
+ * (reference: src/drrt.cpp:47-58, declarations include/tracer.h:15-89).  Plain pointers and
+ * sizes only -- no torch / enoki / pybind types.
+ *
+ * Conventions shared by all entry points
+ *   - every array pointer is a DEVICE pointer (HIP, gfx950) unless stated otherwise;
+ *   - ray arrays (pos, vel, xt, vt, dx, dv, pln_o, pln_d, target) are (n,3) row-major fp32,
+ *     exactly the torch tensors the reference's core/tracer.py hands to enoki
+ *     (core/tracer.py:300-301); outputs have the same layout;
+ *   - `rif` / `sdf` / `grad` are flat fp32[nvox], C-order flatten of the torch (D,H,W) tensor
+ *     (core/tracer.py:299); `res` is a HOST pointer to 3 ints = tuple(rif.shape), used as
+ *     (width,height,depth) with flat index (z*height + y)*width + x (src/volume.cpp:134-141);
+ *   - `h`, `ds` are fp32 scalars (include/tracer.h:20-21 narrows python floats to float);
+ *   - calls are ASYNCHRONOUS on `stream` (a hipStream_t; NULL = the null stream) and never
+ *     allocate, free or synchronise; scratch memory comes from the caller-provided workspace;
+ *   - return value: DRRT_OK or a negative DRRT_ERR_*; drrt_last_error() returns the message
+ *     of the last failing call on this host thread.  The three messages of the reference
+ *     (src/volume.cpp:28,37,115,124) are reproduced verbatim.
+ *
+ * Statistics: `stats` (nullable) is a DEVICE pointer to one drrt_stats that the call zeroes and
+ * fills; read it back after synchronising the stream.  `n_failed > 0` is the condition under
+ * which the reference prints "failed to exit all rays" (src/tracer.cpp:89-90).
+ */
+#ifndef DRRT_HIP_H
+#define DRRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define DRRT_API __attribute__((visibility("default")))
+#else
+#define DRRT_API
+#endif
+
+#define DRRT_OK                0
+#define DRRT_ERR_RES_MISMATCH (-1)  /* "Resolution doesn't match data"  (src/volume.cpp:28,37)  */
+#define DRRT_ERR_BAD_RES      (-2)  /* "volume: invalid resolution!"     (src/volume.cpp:124)    */
+#define DRRT_ERR_ARG          (-3)  /* null pointer / workspace too small / bad flag             */
+#define DRRT_ERR_HIP          (-4)  /* a HIP runtime call failed (message carries hipGetErrorString) */
+
+/* flags (bit-or) */
+#define DRRT_FLAG_NONE         0u
+#define DRRT_FLAG_SORT_RAYS    1u   /* locality-sort rays by entry voxel before marching (results
+                                       are written back in the caller's ray order)                */
+#define DRRT_FLAG_CORRECTED_H  2u   /* adjoint only: divide the gradient-splat term by h (exact
+                                       discrete adjoint).  Default = as written in the reference,
+                                       which omits it (src/volume.cpp:227-243 vs :178)            */
+#define DRRT_FLAG_NO_ZERO      4u   /* adjoint only: accumulate into `grad` without zeroing it
+                                       first (the reference always starts from zeros,
+                                       src/tracer.cpp:401-403)                                    */
+#define DRRT_FLAG_DIRECT_ATOMICS 8u /* adjoint only: bypass the LDS gradient windows and issue
+                                       one global atomic per tap (debug / A-B measurement)        */
+
+typedef struct drrt_stats {
+  unsigned long long ray_steps;  /* sum over rays of march iterations executed while the ray was live */
+  unsigned long long n_failed;   /* rays still live after max_steps                                  */
+  unsigned int       iters;      /* max over rays of iterations = the reference's global loop count  */
+  unsigned int       reserved;
+} drrt_stats;
+
+/* Bytes of device scratch a call over `n` rays may need (0 when flags need none). */
+DRRT_API size_t drrt_workspace_bytes(size_t n, unsigned flags);
+
+/* Message of the last error on this thread ("" if none). */
+DRRT_API const char* drrt_last_error(void);
+
+/* Library / build identification, e.g. "drrt_hip 0.1 gfx950". */
+DRRT_API const char* drrt_version(void);
+
+/* ---- forward marches ------------------------------------------------------------------- */
+
+/* Tracer<false,true>::trace  -- src/tracer.cpp:35-100, bound as TracerC.trace (src/drrt.cpp:51) */
+DRRT_API int drrt_trace_f32(const float* rif, long long nvox, const int res[3], size_t n,
+                   const float* pos, const float* vel, float h, float ds,
+                   float* xt, float* vt,
+                   drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                   unsigned flags, void* stream);
+
+/* Tracer::trace_plane -- src/tracer.cpp:102-172, bound as TracerC.trace_pln (src/drrt.cpp:52).
+ * failmask[i] = 1 for rays that never got flagged escaped (uint8, n entries).                 */
+DRRT_API int drrt_trace_pln_f32(const float* rif, long long nvox, const int res[3], size_t n,
+                       const float* pos, const float* vel,
+                       const float* pln_o, const float* pln_d, float h, float ds,
+                       float* xt, float* vt, uint8_t* failmask,
+                       drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                       unsigned flags, void* stream);
+
+/* Tracer::trace_target -- src/tracer.cpp:174-242, TracerC.trace_target (src/drrt.cpp:54).
+ * Records the state at closest approach to target[i]; dist2 = squared distance there.          */
+DRRT_API int drrt_trace_target_f32(const float* rif, long long nvox, const int res[3], size_t n,
+                          const float* pos, const float* vel, const float* target,
+                          float h, float ds, float* xt, float* vt, float* dist2,
+                          drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                          unsigned flags, void* stream);
+
+/* Tracer::trace_sdf -- src/tracer.cpp:244-310, TracerC.trace_sdf (src/drrt.cpp:53).            */
+DRRT_API int drrt_trace_sdf_f32(const float* rif, const float* sdf, long long nvox, const int res[3],
+                       size_t n, const float* pos, const float* vel, float h, float ds,
+                       float* xt, float* vt,
+                       drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                       unsigned flags, void* stream);
+
+/* Tracer::trace_cable -- src/tracer.cpp:312-382, TracerC.trace_cable (src/drrt.cpp:55).
+ * rif = radial profile fp32[rres] (src/cylinder_volume.cpp).                                    */
+DRRT_API int drrt_trace_cable_f32(const float* rif, size_t rres, float radius, float length, size_t n,
+                         const float* pos, const float* vel, const float* target, float ds,
+                         float* xt, float* vt, float* dist2,
+                         drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                         unsigned flags, void* stream);
+
+/* ---- adjoint marches: accumulate dL/dn into `grad` --------------------------------------- */
+
+/* Tracer::backtrace -- src/tracer.cpp:384-440, TracerC.backtrace (src/drrt.cpp:56).
+ * grad: fp32[nvox]; zeroed by the call unless DRRT_FLAG_NO_ZERO.                                 */
+DRRT_API int drrt_backtrace_f32(const float* rif, long long nvox, const int res[3], size_t n,
+                       const float* xt, const float* vt, const float* dx, const float* dv,
+                       float h, float ds, float* grad,
+                       drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                       unsigned flags, void* stream);
+
+/* Tracer::backtrace_sdf -- src/tracer.cpp:443-509, TracerC.backtrace_sdf (src/drrt.cpp:57).     */
+DRRT_API int drrt_backtrace_sdf_f32(const float* rif, const float* sdf, long long nvox, const int res[3],
+                           size_t n, const float* xt, const float* vt,
+                           const float* dx, const float* dv, float h, float ds, float* grad,
+                           drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                           unsigned flags, void* stream);
+
+/* Tracer::backtrace_cable -- src/tracer.cpp:511-567, TracerC.backtrace_cable (src/drrt.cpp:58).
+ * grad: fp32[rres].                                                                             */
+DRRT_API int drrt_backtrace_cable_f32(const float* rif, size_t rres, float radius, float length, size_t n,
+                             const float* xt, const float* vt, const float* dx, const float* dv,
+                             float ds, float* grad,
+                             drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                             unsigned flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRRT_HIP_H */

@@ -1,0 +1,78 @@
+"""Deterministic synthetic scenes and ray sets shared by the parity tests (numpy only).
+
+Scene shapes follow the reference's workloads: Luneburg ball n(r)=sqrt(2-r^2)
+(/root/reference/core/fiber_opt.py:165-166), smooth tomography-like field in [1, 1.0003]
+(value range of data/fuel_injection_64.npy), uniform medium (src/test.cpp:117-146)."""
+import numpy as np
+
+
+def luneburg(R, span=1.0):
+    g = np.linspace(0.0, span, R)
+    Z, Y, X = np.meshgrid(g, g, g, indexing="ij")          # torch (D,H,W) order: rif[z,y,x]
+    r = np.sqrt((X - span / 2) ** 2 + (Y - span / 2) ** 2 + (Z - span / 2) ** 2) / (span / 2)
+    return np.sqrt(2.0 - np.minimum(r, 1.0) ** 2).astype(np.float32)
+
+
+def smooth_field(R, seed=0, amp=0.2):
+    """Band-limited random field 1 + amp*U, asymmetric in x,y,z (catches axis-order bugs)."""
+    rng = np.random.default_rng(seed)
+    g = np.linspace(0.0, 1.0, R)
+    Z, Y, X = np.meshgrid(g, g, g, indexing="ij")
+    f = np.zeros((R, R, R))
+    for _ in range(6):
+        k = rng.uniform(0.5, 3.0, 3) * np.pi
+        ph = rng.uniform(0, 2 * np.pi, 3)
+        f += rng.uniform(0.3, 1.0) * np.sin(k[0] * X + ph[0]) * np.sin(k[1] * Y + ph[1]) * np.sin(k[2] * Z + ph[2])
+    f = (f - f.min()) / (f.max() - f.min())
+    return (1.0 + amp * f).astype(np.float32)
+
+
+def sphere_sdf(R, span=1.0, radius=0.4):
+    g = np.linspace(0.0, span, R)
+    Z, Y, X = np.meshgrid(g, g, g, indexing="ij")
+    return (np.sqrt((X - span / 2) ** 2 + (Y - span / 2) ** 2 + (Z - span / 2) ** 2) - radius).astype(np.float32)
+
+
+def plane_rays(n, span, ds, seed=0, axis=1, offset=-0.3, tilt=0.05, lo=0.05, hi=0.95):
+    """Jittered plane source just OUTSIDE the face `axis`=0 (offset*ds before it), travelling along
+    +axis with a small tilt.  Starting off-face by a fraction of a step keeps the adjoint's
+    termination test (escaped(x,-v), src/tracer.cpp:425) away from floating-point ties."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(lo * span, hi * span, (n, 3))
+    pos[:, axis] = offset * ds
+    vel = rng.normal(0, tilt, (n, 3))
+    vel[:, axis] = 1.0
+    vel /= np.linalg.norm(vel, axis=1, keepdims=True)
+    return pos.astype(np.float32), vel.astype(np.float32)
+
+
+def cube_rays(n_per_face, span, ds, seed=0, tilt=0.1):
+    """Six views (one per face), like source.rand_rays_cube (/root/reference/core/source.py:398-412)."""
+    ps, vs = [], []
+    for f in range(6):
+        axis, sign = f // 2, 1 - 2 * (f % 2)
+        p, v = plane_rays(n_per_face, span, ds, seed=seed + f, axis=axis, tilt=tilt)
+        if sign < 0:
+            p[:, axis] = span - p[:, axis]
+            v[:, axis] = -v[:, axis]
+        ps.append(p); vs.append(v)
+    return np.concatenate(ps), np.concatenate(vs)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel(); b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def step_flip_report(xt, vt, xt_ref, vt_ref, ds, tol):
+    """Fraction of rays whose exit sample differs from the reference by more than `tol` and
+    how many of those are explained by exiting one march step earlier/later (xt differs by
+    ~ +-ds*v): the boundary test `p < (res-1)*h` is discontinuous, so an ulp of difference in
+    the trajectory legitimately flips the exit step."""
+    d = np.linalg.norm(xt.astype(np.float64) - xt_ref.astype(np.float64), axis=1)
+    bad = d > tol
+    if not bad.any():
+        return 0.0, 0.0
+    step = np.linalg.norm(ds * vt_ref[bad].astype(np.float64), axis=1)
+    explained = np.abs(d[bad] - step) < 10 * tol + 1e-3 * step
+    return float(bad.mean()), float((bad.sum() - explained.sum()) / len(d))

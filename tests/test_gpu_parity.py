@@ -1,0 +1,262 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via drrt.TracerC) against the CPU
+oracle on identical seeded inputs.  Tolerances (fp32 path, stated per test):
+
+  forward exit state     |x - x_f64| <= 2e-5 * span  (positions are O(span); ~300-step fp32 march)
+  exit-step flips        <= 0.5 % of rays may exit one step earlier/later than the oracle
+                         (discontinuous boundary test); none unexplained
+  adjoint dL/dn          rel-L2 <= 1e-4 vs the fp64 oracle fed the SAME exit rays (north_star)
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.fixture(scope="module")
+def drrt_mod(gpu):
+    from adjointnonlinearraytracing_amd import drrt
+    drrt.options.check_failed = False
+    return drrt
+
+
+def _scene(kind, R):
+    if kind == "luneburg":
+        return cases.luneburg(R)
+    if kind == "smooth":
+        return cases.smooth_field(R, seed=3)
+    if kind == "uniform":
+        return np.ones((R, R, R), np.float32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,R,n", [("luneburg", 33, 4096), ("smooth", 33, 4096), ("uniform", 17, 1024),
+                                      ("luneburg", 65, 20000)])
+@pytest.mark.parametrize("sort", [False, True])
+def test_trace_matches_oracle(gpu, oracle, drrt_mod, kind, R, n, sort):
+    span = 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = _scene(kind, R)
+    pos, vel = cases.cube_rays(n // 6 + 1, span, ds, seed=1)
+    drrt_mod.options.sort_rays = sort
+    xt, vt = drrt_mod.TracerC().trace(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+    st = drrt_mod.read_stats()
+    xt, vt = xt.cpu().numpy(), vt.cpu().numpy()
+    ref = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float64)
+    frac_bad, frac_unexplained = cases.step_flip_report(xt, vt, ref["xt"], ref["vt"], ds, tol=2e-5 * span)
+    assert frac_unexplained == 0.0
+    assert frac_bad <= 0.005
+    ok = np.linalg.norm(xt - ref["xt"], axis=1) <= 2e-5 * span
+    assert np.abs(vt[ok] - ref["vt"][ok]).max() <= 2e-5
+    assert st["n_failed"] == ref["n_failed"] == 0
+    # ray-steps metric: same count as the oracle up to the flipped rays
+    assert abs(st["ray_steps"] - int(ref["steps"].sum())) <= max(2, int(0.005 * len(pos)))
+    assert abs(st["iters"] - ref["iters"]) <= 1
+    # fp32 oracle (literal reference expression order) agrees to the same tolerance
+    ref32 = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float32)
+    fb32, fu32 = cases.step_flip_report(xt, vt, ref32["xt"], ref32["vt"], ds, tol=4e-5 * span)
+    assert fu32 == 0.0 and fb32 <= 0.005
+
+
+@pytest.mark.parametrize("kind,R,n", [("luneburg", 33, 6000), ("smooth", 33, 6000), ("uniform", 33, 1024)])
+@pytest.mark.parametrize("sort", [False, True])
+@pytest.mark.parametrize("corrected", [False, True])
+def test_backtrace_matches_oracle(gpu, oracle, drrt_mod, kind, R, n, sort, corrected):
+    span = 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = _scene(kind, R)
+    pos, vel = cases.cube_rays(n // 6, span, ds, seed=5)
+    drrt_mod.options.sort_rays = sort
+    drrt_mod.options.corrected_h = corrected
+    try:
+        T = drrt_mod.TracerC()
+        xt, vt = T.trace(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+        rng = np.random.default_rng(7)
+        dx = rng.normal(size=pos.shape).astype(np.float32)
+        dv = rng.normal(size=pos.shape).astype(np.float32)
+        g = T.backtrace(_t(rif, gpu), rif.shape, xt, vt, _t(dx, gpu), _t(dv, gpu), h, ds)
+        st = drrt_mod.read_stats()
+    finally:
+        drrt_mod.options.corrected_h = False
+    ref = oracle.backtrace(rif, rif.shape, xt.cpu().numpy(), vt.cpu().numpy(), dx, dv, h, ds,
+                           dtype=np.float64, corrected_h=corrected)
+    err = cases.rel_l2(g.cpu().numpy(), ref["grad"])
+    assert err <= 1e-4, f"rel-L2 {err}"
+    assert abs(st["ray_steps"] - ref["steps_total"]) <= max(2, int(0.005 * len(pos)))
+    if kind == "uniform":
+        # KAT: grad n = 0 => value splat 0 and the gradient-splat weights sum to 0
+        assert abs(float(g.sum())) <= 1e-3 * float(g.abs().sum() + 1e-30)
+
+
+def test_uniform_medium_kat(gpu, drrt_mod):
+    """src/test.cpp:117-146 workload: rif=1, h=1, 33^3, rays on z=0 along +z, ds=0.5.
+    Straight rays; exit at the first sample with z >= 32 => 64 steps, xt.z = 32 exactly."""
+    R, h, ds = 33, 1.0, 0.5
+    rif = np.ones((R, R, R), np.float32)
+    g = np.linspace(0.5, 31.5, 16, dtype=np.float32)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    pos = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size, np.float32)], -1)
+    vel = np.tile(np.array([[0, 0, 1]], np.float32), (len(pos), 1))
+    for sort in (False, True):
+        drrt_mod.options.sort_rays = sort
+        xt, vt = drrt_mod.TracerC().trace(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+        st = drrt_mod.read_stats()
+        assert torch.equal(xt.cpu()[:, 2], torch.full((len(pos),), 32.0))
+        assert torch.equal(xt.cpu()[:, :2], torch.from_numpy(pos[:, :2]))
+        assert torch.equal(vt.cpu(), torch.from_numpy(vel))
+        assert st["ray_steps"] == 64 * len(pos) and st["iters"] == 64 and st["n_failed"] == 0
+
+
+def test_trace_plane_and_target(gpu, oracle, drrt_mod):
+    R, span = 33, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = cases.luneburg(R)
+    pos, vel = cases.plane_rays(5000, span, ds, seed=11)
+    # sensor plane inside the volume at y = 0.7*span, normal +y
+    po = np.tile(np.array([[0.5, 0.7, 0.5]], np.float32) * span, (len(pos), 1))
+    pd = np.tile(np.array([[0, 1, 0]], np.float32), (len(pos), 1))
+    drrt_mod.options.sort_rays = True
+    T = drrt_mod.TracerC()
+    xt, vt, fm = T.trace_pln(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), _t(po, gpu), _t(pd, gpu), h, ds)
+    ref = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float64, mode="plane", pln_o=po, pln_d=pd)
+    fb, fu = cases.step_flip_report(xt.cpu().numpy(), vt.cpu().numpy(), ref["xt"], ref["vt"], ds, 2e-5)
+    assert fu == 0.0 and fb <= 0.005
+    assert (fm.cpu().numpy().astype(bool) == ref["failmask"]).all()
+    # target = a point beyond the far face: closest approach happens in free flight after escape,
+    # so this exercises the global-loop-count coupling (src/tracer.cpp:225-227)
+    tg = np.tile(np.array([[0.5, 1.3, 0.5]], np.float32) * span, (len(pos), 1))
+    xt2, vt2, d2 = T.trace_target(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), _t(tg, gpu), h, ds)
+    st = drrt_mod.read_stats()
+    ref2 = oracle.trace_target(rif, rif.shape, pos, vel, tg, h, ds, dtype=np.float64)
+    assert abs(st["iters"] - ref2["iters"]) <= 1
+    fb, fu = cases.step_flip_report(xt2.cpu().numpy(), vt2.cpu().numpy(), ref2["xt"], ref2["vt"], ds, 2e-5)
+    assert fu == 0.0 and fb <= 0.01
+    ok = np.linalg.norm(xt2.cpu().numpy() - ref2["xt"], axis=1) <= 2e-5
+    assert np.abs(d2.cpu().numpy()[ok] - ref2["dist2"][ok]).max() <= 1e-5
+
+
+def test_sdf_variants(gpu, oracle, drrt_mod):
+    R, span = 33, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = cases.luneburg(R)
+    sdf = cases.sphere_sdf(R, span, 0.4)
+    # rays start INSIDE the sdf<0 region (trace_sdf's `inside` is the sdf sign after step 1)
+    rng = np.random.default_rng(2)
+    d = rng.normal(size=(4000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pos = (0.5 * span + 0.2 * span * rng.uniform(0, 1, (4000, 1)) ** (1 / 3) * d).astype(np.float32)
+    v = rng.normal(size=(4000, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    vel = v.astype(np.float32)
+    drrt_mod.options.sort_rays = True
+    T = drrt_mod.TracerC()
+    xt, vt = T.trace_sdf(_t(rif, gpu), _t(sdf, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+    ref = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float64, mode="sdf", sdf=sdf)
+    fb, fu = cases.step_flip_report(xt.cpu().numpy(), vt.cpu().numpy(), ref["xt"], ref["vt"], ds, 2e-5)
+    assert fu == 0.0 and fb <= 0.01
+    dx = rng.normal(size=pos.shape).astype(np.float32); dv = rng.normal(size=pos.shape).astype(np.float32)
+    g = T.backtrace_sdf(_t(rif, gpu), _t(sdf, gpu), rif.shape, xt, vt, _t(dx, gpu), _t(dv, gpu), h, ds)
+    refb = oracle.backtrace(rif, rif.shape, xt.cpu().numpy(), vt.cpu().numpy(), dx, dv, h, ds,
+                            dtype=np.float64, sdf=sdf)
+    # the sdf stop test (dist >= 0 crossing) is discontinuous like the box test: a handful of
+    # rays may stop one step apart, so the tolerance is looser than for the box adjoint
+    assert cases.rel_l2(g.cpu().numpy(), refb["grad"]) <= 5e-3
+
+
+def test_cable_variants(gpu, oracle, drrt_mod):
+    rres, radius, length = 65, 1.0, 8.0
+    ds = radius / rres / 2                                  # core/fiber_opt.py:156
+    r = np.linspace(0, 1, rres)
+    prof = np.sqrt(2.0 - r ** 2).astype(np.float32)         # Luneburg-like GRIN profile
+    rng = np.random.default_rng(4)
+    n = 3000
+    ang = rng.uniform(0, 2 * np.pi, n); rad = 0.8 * radius * np.sqrt(rng.uniform(0, 1, n))
+    pos = np.stack([radius + rad * np.cos(ang), np.full(n, 0.37 * ds), radius + rad * np.sin(ang)], -1).astype(np.float32)
+    vel = rng.normal(0, 0.05, (n, 3)); vel[:, 1] = 1.0
+    vel = (vel / np.linalg.norm(vel, axis=1, keepdims=True)).astype(np.float32)
+    tg = np.stack([np.full(n, radius), np.full(n, 0.75 * length), np.full(n, radius)], -1).astype(np.float32)
+    T = drrt_mod.TracerC()
+    xt, vt, d2 = T.trace_cable(_t(prof, gpu), radius, length, _t(pos, gpu), _t(vel, gpu), _t(tg, gpu), ds)
+    ref = oracle.trace_cable(prof, radius, length, pos, vel, tg, ds, dtype=np.float64)
+    fb, fu = cases.step_flip_report(xt.cpu().numpy(), vt.cpu().numpy(), ref["xt"], ref["vt"], ds, 5e-5)
+    assert fu == 0.0 and fb <= 0.01
+    dx = rng.normal(size=pos.shape).astype(np.float32); dv = rng.normal(size=pos.shape).astype(np.float32)
+    g = T.backtrace_cable(_t(prof, gpu), radius, length, xt, vt, _t(dx, gpu), _t(dv, gpu), ds)
+    refb = oracle.backtrace_cable(prof, radius, length, xt.cpu().numpy(), vt.cpu().numpy(), dx, dv, ds,
+                                  dtype=np.float64)
+    assert cases.rel_l2(g.cpu().numpy(), refb["grad"]) <= 1e-3
+
+
+def test_autograd_function_contract(gpu, oracle, drrt_mod):
+    """core/tracer.py:294-335 contract: apply(rif,x,v,h,ds) -> (xt,vt); backward gives drif only;
+    h, ds arrive as numpy float64 scalars (core/luneburg_opt.py:87, :48-49)."""
+    from adjointnonlinearraytracing_amd import tracer
+    R, span = 17, 20.0
+    h = span / np.maximum(R - 1, 1); ds = h / 2
+    rif_np = cases.luneburg(R, span=1.0)
+    pos, vel = cases.plane_rays(2000, span, ds, seed=3)
+    rif = _t(rif_np, gpu).requires_grad_(True)
+    x = _t(pos, gpu).requires_grad_(True)
+    xt, vt = tracer.BackTracerC.apply(rif, x, _t(vel, gpu), h, ds)
+    assert xt.shape == (2000, 3) and vt.shape == (2000, 3) and xt.device == rif.device
+    loss = ((xt - 0.5 * span) ** 2).sum() / 2000 / span + vt.sum() * 0.01
+    loss.backward()
+    assert rif.grad is not None and rif.grad.shape == rif.shape
+    assert x.grad is None
+    gx = (2 * (xt.detach() - 0.5 * span) / 2000 / span).cpu().numpy()
+    gv = np.full_like(gx, 0.01)
+    ref = oracle.backtrace(rif_np, rif_np.shape, xt.detach().cpu().numpy(), vt.detach().cpu().numpy(),
+                           gx, gv, h, ds, dtype=np.float64)
+    assert cases.rel_l2(rif.grad.cpu().numpy().ravel(), ref["grad"]) <= 1e-4
+
+
+def test_errors_and_edge_cases(gpu, drrt_mod):
+    T = drrt_mod.TracerC()
+    rif = torch.ones(8, 8, 8, device=gpu)
+    x = torch.rand(10, 3, device=gpu); v = torch.rand(10, 3, device=gpu)
+    with pytest.raises(RuntimeError, match="Resolution doesn't match data"):     # src/volume.cpp:37
+        T.trace(rif, (8, 8, 9), x, v, 1.0, 0.5)
+    with pytest.raises(RuntimeError, match="invalid resolution"):                # src/volume.cpp:124
+        T.trace(torch.ones(8, 1, 1, device=gpu), (1, 1, 8), x, v, 1.0, 0.5)
+    # empty ray set
+    e = torch.empty(0, 3, device=gpu)
+    xt, vt = T.trace(rif, rif.shape, e, e, 1.0, 0.5)
+    assert xt.shape == (0, 3)
+    g = T.backtrace(rif, rif.shape, e, e, e, e, 1.0, 0.5)
+    assert g.shape == (512,) and float(g.abs().sum()) == 0.0
+    # ragged: n not a multiple of the block; rays that never enter keep xt=pos, vt=vel (Q6)
+    pos = torch.tensor([[-1.0, 3.0, 3.0], [3.0, 3.0, 3.0], [20.0, 3.0, 3.0]], device=gpu)
+    vel = torch.tensor([[-1.0, 0.0, 0.0], [1.0, 0.0, 0.0], [1.0, 0.0, 0.0]], device=gpu)
+    xt, vt = T.trace(rif, rif.shape, pos, vel, 1.0, 0.5)
+    assert torch.equal(xt[0], pos[0]) and torch.equal(xt[2], pos[2])
+    assert float(xt[1, 0]) == 7.0
+    # non-contiguous / strided views are accepted (core/luneburg_opt.py:57 builds them with cat/split)
+    big = torch.rand(40, 6, device=gpu) * 6
+    xt2, _ = T.trace(rif, rif.shape, big[:, :3], big[:, 3:], 1.0, 0.5)
+    xt3, _ = T.trace(rif, rif.shape, big[:, :3].contiguous(), big[:, 3:].contiguous(), 1.0, 0.5)
+    assert torch.equal(xt2, xt3)
+    # CPU tensors are refused by TracerC (no silent fallback) and served by TracerS via the GPU
+    with pytest.raises(RuntimeError):
+        T.trace(rif.cpu(), rif.shape, x.cpu(), v.cpu(), 1.0, 0.5)
+    xs, vs = drrt_mod.TracerS().trace(rif.cpu(), rif.shape, pos.cpu(), vel.cpu(), 1.0, 0.5)
+    assert xs.device.type == "cpu" and torch.equal(xs, xt.cpu())
+
+
+def test_shard_sum_equals_single(gpu, drrt_mod):
+    """the sharded adjoint is a pure sum -- k shards accumulated with
+    DRRT_FLAG_NO_ZERO semantics must equal the single-shard grid up to fp32 atomic ordering."""
+    R, span = 33, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = _t(cases.smooth_field(R, seed=9), gpu)
+    pos, vel = cases.cube_rays(1000, span, ds, seed=21)
+    T = drrt_mod.TracerC()
+    xt, vt = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+    dx = torch.randn_like(xt); dv = torch.randn_like(vt)
+    full = T.backtrace(rif, rif.shape, xt, vt, dx, dv, h, ds)
+    parts = sum(T.backtrace(rif, rif.shape, xt[s], vt[s], dx[s], dv[s], h, ds)
+                for s in (slice(0, 1500), slice(1500, 4200), slice(4200, None)))
+    assert cases.rel_l2(parts.cpu().numpy(), full.cpu().numpy()) <= 1e-5
