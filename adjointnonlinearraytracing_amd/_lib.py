@@ -47,7 +47,12 @@ SIGNATURES = {
     "drrt_backtrace_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
     "drrt_backtrace_sdf_f32": (_i, [_vp, _vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
     "drrt_backtrace_cable_f32": (_i, [_vp, _sz, _f, _f, _sz, _vp, _vp, _vp, _vp, _f, _vp] + _tail),
+    "drrt_profile_begin": (_i, [_i]),
+    "drrt_profile_collect": (_i, [_vp, _vp, _i]),
+    "drrt_profile_end": (None, []),
 }
+
+PROF_NAMES = {1: "trace", 2: "backtrace", 3: "sort", 4: "zero"}
 
 _lib: Optional[C.CDLL] = None
 
@@ -69,6 +74,14 @@ def load() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def profile_collect(max_out: int = 4096):
+    """-> list of (kernel name, ms) in launch order since the last collect (synchronises)."""
+    ids = (C.c_int * max_out)()
+    ms = (C.c_float * max_out)()
+    n = load().drrt_profile_collect(ids, ms, max_out)
+    return [(PROF_NAMES.get(ids[i], str(ids[i])), float(ms[i])) for i in range(n)]
 
 
 def last_error() -> str:

@@ -1,4 +1,4 @@
-// drrt_device.h -- device-side building blocks of the gfx950 eikonal ray-march kernels.
+// drrt_device.h -- per-ray building blocks of the gfx950 eikonal ray-march kernels.
 //
 // What the reference computes (file:line = /root/reference/...):
 //   volume::eval_grad  src/volume.cpp:101-181   trilinear n(p) and grad n(p)
@@ -6,15 +6,27 @@
 //   volume::splat      src/volume.cpp:182-244   adjoint of eval_grad w.r.t. the voxels
 //   volume::inbounds / escaped  src/volume.cpp:246-271
 //   cylinder_volume::*  src/cylinder_volume.cpp:26-170
+//   one forward / adjoint march iteration: src/tracer.cpp:68-86, :420-435
 //
 // How it is computed here: the 8 taps are fetched once per ray-step and n, grad n and the
-// three mixed partials are all derived from ONE factored lerp tree (differences first,
-// ~27 flops instead of the ~150 of the expanded weight products); the 16 scatter_adds of
-// volume::splat are fused into 8 corner contributions.  Differences-first also avoids the
-// cancellation of the reference's (sum of 4 products) - (sum of 4 products) form.
+// three mixed partials all come from ONE factored lerp tree (differences first, ~27 flops
+// instead of the ~150 of the expanded weight products; differences-first also avoids the
+// cancellation of the reference's (sum of 4 products) - (sum of 4 products) form); the 16
+// scatter_adds of volume::splat are fused into 8 corner contributions.
+//
+// ARITHMETIC CONTRACT ("factored fp32 spec"): every expression below is an explicit sequence of
+// IEEE-754 binary32 operations (+, -, *, fmaf, floorf, sqrtf, /, conversions); the library is
+// built with -ffp-contract=off so the compiler adds no fusion of its own.  The CPU oracle's
+// `factored` arithmetic mode (oracle/drrt_oracle_impl.h) restates the same sequence in plain C,
+// which makes forward trajectories and exit steps comparable BIT FOR BIT between the GPU and the
+// oracle (only the order of the adjoint's atomic sums differs).  Functions that need nothing
+// device-specific are __host__ __device__ so that tests/hostcheck can run this very code on the
+// CPU; the package itself never does (no CPU compute path).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#define DRRT_HD __host__ __device__ __forceinline__
 
 namespace drrt {
 
@@ -24,8 +36,9 @@ struct Vol {
   const float* data;
   int W, H, D;          // res[0], res[1], res[2]  (x, y, z extents; x is memory-contiguous)
   int sy, sz;           // element strides of y and z: W, W*H
-  float inv_h;          // 1/h   (reference: rcp(h_), src/volume.cpp:128)
-  float bx, by, bz;     // (res-1)*h : upper bounds used by inbounds/escaped (src/volume.cpp:252-254)
+  float inv_h;          // 1.0f/h   (reference: rcp(h_), src/volume.cpp:128)
+  float inv_h2;         // inv_h*inv_h
+  float bx, by, bz;     // (float)(res-1)*h : bounds of inbounds/escaped (src/volume.cpp:252-254)
 };
 
 struct Cell {
@@ -34,15 +47,27 @@ struct Cell {
   float wx, wy, wz;     // fractional weights w0 = pm - floor(pm)  (unclamped, Q11)
 };
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+DRRT_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// float -> int with the saturating behaviour of v_cvt_i32_f32 (NaN -> 0), also on the host
+DRRT_HD int f2i_sat(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)f;
+#else
+  if (!(f == f)) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)f;
+#endif
+}
 
 // src/volume.cpp:128-141: pm = p*rcp(h); pos = floor2int(pm); w0 = pm - pos; clamp indices.
-__device__ __forceinline__ Cell locate(const Vol& V, float px, float py, float pz) {
+DRRT_HD Cell locate(const Vol& V, float px, float py, float pz) {
   Cell c;
   float fx = px * V.inv_h, fy = py * V.inv_h, fz = pz * V.inv_h;
   float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
   c.wx = fx - flx; c.wy = fy - fly; c.wz = fz - flz;
-  int ix = (int)flx, iy = (int)fly, iz = (int)flz;       // v_cvt_i32_f32 saturates, NaN -> 0
+  int ix = f2i_sat(flx), iy = f2i_sat(fly), iz = f2i_sat(flz);
   int x0 = clampi(ix, 0, V.W - 1), x1 = clampi(ix + 1, 0, V.W - 1);
   int y0 = clampi(iy, 0, V.H - 1), y1 = clampi(iy + 1, 0, V.H - 1);
   int z0 = clampi(iz, 0, V.D - 1), z1 = clampi(iz + 1, 0, V.D - 1);
@@ -53,7 +78,7 @@ __device__ __forceinline__ Cell locate(const Vol& V, float px, float py, float p
 
 struct Taps { float v000, v100, v010, v110, v001, v101, v011, v111; };
 
-__device__ __forceinline__ Taps fetch(const float* __restrict__ d, const Cell& c) {
+DRRT_HD Taps fetch(const float* __restrict__ d, const Cell& c) {
   Taps t;
   const float* p = d + c.base;
   t.v000 = p[0];            t.v100 = p[c.ox];
@@ -63,11 +88,11 @@ __device__ __forceinline__ Taps fetch(const float* __restrict__ d, const Cell& c
   return t;
 }
 
-// n and RAW gradient / mixed partials (not yet divided by h / h^2).
+// n and RAW gradient / mixed partials (not yet multiplied by 1/h, 1/h^2).
 struct Sample { float n, gx, gy, gz, hxy, hxz, hyz; };
 
 template <bool WITH_HESS>
-__device__ __forceinline__ Sample interp(const Taps& t, float wx, float wy, float wz) {
+DRRT_HD Sample interp(const Taps& t, float wx, float wy, float wz) {
   Sample s;
   // x-differences at the four (y,z) edges
   float d00 = t.v100 - t.v000, d10 = t.v110 - t.v010, d01 = t.v101 - t.v001, d11 = t.v111 - t.v011;
@@ -96,16 +121,19 @@ __device__ __forceinline__ Sample interp(const Taps& t, float wx, float wy, floa
 }
 
 // src/volume.cpp:246-256
-__device__ __forceinline__ bool inbounds(const Vol& V, float px, float py, float pz) {
+DRRT_HD bool inbounds(const Vol& V, float px, float py, float pz) {
   return (px >= 0.f) & (py >= 0.f) & (pz >= 0.f) & (px < V.bx) & (py < V.by) & (pz < V.bz);
 }
 // src/volume.cpp:258-271
-__device__ __forceinline__ bool escaped(const Vol& V, float px, float py, float pz,
-                                        float vx, float vy, float vz) {
+DRRT_HD bool escaped(const Vol& V, float px, float py, float pz, float vx, float vy, float vz) {
   bool ex = ((px < 0.f) & (vx < 0.f)) | ((px >= V.bx) & (vx > 0.f));
   bool ey = ((py < 0.f) & (vy < 0.f)) | ((py >= V.by) & (vy > 0.f));
   bool ez = ((pz < 0.f) & (vz < 0.f)) | ((pz >= V.bz) & (vz > 0.f));
   return ex | ey | ez;
+}
+
+DRRT_HD float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+  return fmaf(az, bz, fmaf(ay, by, ax * bx));
 }
 
 // Fused volume::splat (src/volume.cpp:217-243): contribution of (val, grad) to the 8 corners.
@@ -113,10 +141,9 @@ __device__ __forceinline__ bool escaped(const Vol& V, float px, float py, float 
 // with X_0 = 1-wx, X_1 = wx, sign = - for index 0, + for index 1.
 struct Corners { float c000, c100, c010, c110, c001, c101, c011, c111; };
 
-__device__ __forceinline__ Corners splat_weights(float wx, float wy, float wz, float val,
-                                                 float gx, float gy, float gz) {
+DRRT_HD Corners splat_weights(float wx, float wy, float wz, float val, float gx, float gy, float gz) {
   float x1 = wx, x0 = 1.f - wx, y1 = wy, y0 = 1.f - wy, z1 = wz, z0 = 1.f - wz;
-  float a0 = fmaf(val, x0, -gx), a1 = fmaf(val, x1, gx);          // val*X_a +- gx
+  float a0 = fmaf(val, x0, -gx), a1 = fmaf(val, x1, gx);          // val*X_a -+ gx
   float yz00 = y0 * z0, yz10 = y1 * z0, yz01 = y0 * z1, yz11 = y1 * z1;
   float gyz0 = gy * z0, gyz1 = gy * z1, gzy0 = gz * y0, gzy1 = gz * y1;
   float b00 = -gyz0 - gzy0, b10 = gyz0 - gzy1, b01 = gzy0 - gyz1, b11 = gyz1 + gzy1;
@@ -128,6 +155,349 @@ __device__ __forceinline__ Corners splat_weights(float wx, float wy, float wz, f
   return c;
 }
 
+// ---------------------------------------------------------------------------------------------
+// one forward march iteration (src/tracer.cpp:68-86; plane :144-145; sdf :287-288)
+// MODE 0 = trace, 1 = trace_plane, 2 = trace_sdf, 3 = trace_target (closest-approach tracking)
+// ---------------------------------------------------------------------------------------------
+struct FwdState {
+  float x, y, z, vx, vy, vz;         // marching state
+  float xtx, xty, xtz, vtx, vty, vtz;  // recorded exit / closest-approach state
+  float aux0, aux1, aux2, aux3, aux4, aux5;  // MODE 1: plane origin+normal; MODE 3: target (aux0..2), best dist2 (aux3)
+  bool inside, esc;
+};
+
+DRRT_HD void fwd_init(const Vol& V, FwdState& s) {
+  s.xtx = s.x; s.xty = s.y; s.xtz = s.z; s.vtx = s.vx; s.vty = s.vy; s.vtz = s.vz;   // :56-57
+  s.inside = inbounds(V, s.x, s.y, s.z);                                              // :61
+  s.esc = false;                                                                      // :62
+}
+
+template <int MODE>
+DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s) {
+  float n = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+  if (s.inside) {                                                           // masked gather (Q4)
+    Cell c = locate(V, s.x, s.y, s.z);
+    Sample q = interp<false>(fetch(V.data, c), c.wx, c.wy, c.wz);
+    n = q.n; gx = q.gx * V.inv_h; gy = q.gy * V.inv_h; gz = q.gz * V.inv_h;
+  }
+  const float dsn = ds * n;
+  s.vx = fmaf(dsn, gx, s.vx); s.vy = fmaf(dsn, gy, s.vy); s.vz = fmaf(dsn, gz, s.vz);   // :70
+  s.x = fmaf(ds, s.vx, s.x); s.y = fmaf(ds, s.vy, s.y); s.z = fmaf(ds, s.vz, s.z);      // :71
+  bool cur_inside;
+  if (MODE == 2) {                                                          // :287-288
+    float d = 0.f;
+    if (s.inside) {
+      Cell c = locate(V, s.x, s.y, s.z);
+      d = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n;
+    }
+    cur_inside = d < 0.f;
+  } else {
+    cur_inside = inbounds(V, s.x, s.y, s.z);                                // :73
+    if (MODE == 1) {                                                        // :144-145
+      float d = dot3(s.x - s.aux0, s.y - s.aux1, s.z - s.aux2, s.aux3, s.aux4, s.aux5);
+      cur_inside = cur_inside & !(d > 0.f);
+    }
+  }
+  const bool cross = s.inside & !cur_inside;                                // :74
+  s.esc = s.esc | cross | escaped(V, s.x, s.y, s.z, s.vx, s.vy, s.vz);      // :75-76
+  if (MODE == 3) {                                                          // :216-227
+    float ex = s.x - s.aux0, ey = s.y - s.aux1, ez = s.z - s.aux2;
+    float cur = dot3(ex, ey, ez, ex, ey, ez);
+    if (cur < s.aux3) { s.xtx = s.x; s.xty = s.y; s.xtz = s.z; s.vtx = s.vx; s.vty = s.vy; s.vtz = s.vz; s.aux3 = cur; }
+  } else if (cross) {                                                       // :79-80
+    s.xtx = s.x; s.xty = s.y; s.xtz = s.z; s.vtx = s.vx; s.vty = s.vy; s.vtz = s.vz;
+  }
+  s.inside = cur_inside;                                                    // :86
+}
+
+// ---------------------------------------------------------------------------------------------
+// one adjoint march iteration (src/tracer.cpp:420-435; sdf :488-497).  Returns true when the ray
+// is still active after the step, in which case (c, w) is its contribution to dL/dn: add the
+// 8 corner values `w` at the 8 taps of cell `c`.
+// ---------------------------------------------------------------------------------------------
+struct AdjState {
+  float x, y, z, vx, vy, vz;
+  float lx, ly, lz, mx, my, mz;      // lambda (dL/dx), mu (dL/dv)
+  bool active, outside;
+};
+
+DRRT_HD void adj_init(const Vol& V, float ds, float dxx, float dxy, float dxz,
+                      float dvx, float dvy, float dvz, AdjState& s) {
+  s.lx = dxx; s.ly = dxy; s.lz = dxz;                                                   // :409
+  s.mx = fmaf(ds, dxx, dvx); s.my = fmaf(ds, dxy, dvy); s.mz = fmaf(ds, dxz, dvz);      // :410
+  s.active = !escaped(V, s.x, s.y, s.z, -s.vx, -s.vy, -s.vz);                           // :413-414
+  s.outside = false;
+}
+
+template <int MODE>   // 0 = backtrace, 1 = backtrace_sdf
+DRRT_HD bool adj_step(const Vol& V, const float* __restrict__ sdf, float ds, float grad_scale,
+                      AdjState& s, Cell& c, Corners& w) {
+  s.x = fmaf(-ds, s.vx, s.x); s.y = fmaf(-ds, s.vy, s.y); s.z = fmaf(-ds, s.vz, s.z);   // :420
+  c = locate(V, s.x, s.y, s.z);
+  const Sample q = interp<true>(fetch(V.data, c), c.wx, c.wy, c.wz);                    // :421-422
+  const float n = q.n, gx = q.gx * V.inv_h, gy = q.gy * V.inv_h, gz = q.gz * V.inv_h;
+  const float mdsn = -ds * n;
+  s.vx = fmaf(mdsn, gx, s.vx); s.vy = fmaf(mdsn, gy, s.vy); s.vz = fmaf(mdsn, gz, s.vz); // :423
+  bool active = !escaped(V, s.x, s.y, s.z, -s.vx, -s.vy, -s.vz);                        // :425
+  if (MODE == 1) {                                                                      // :488-497
+    bool now_out = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n >= 0.f;
+    active = active & !((!s.outside) & now_out);
+    s.outside = now_out;
+  }
+  s.active = active;
+  if (!active) return false;                                                            // :426-428
+  const float dn = dot3(s.mx, s.my, s.mz, gx, gy, gz);                                  // :430
+  const float nds = (n * ds) * grad_scale;
+  w = splat_weights(c.wx, c.wy, c.wz, dn * ds, nds * s.mx, nds * s.my, nds * s.mz);     // :431-432
+  // la += ds*(dn*grad n + n*H*mu), H = mixed partials / h^2, zero diagonal (:434, Q10)
+  const float hxy = q.hxy * V.inv_h2, hxz = q.hxz * V.inv_h2, hyz = q.hyz * V.inv_h2;
+  const float hmx = fmaf(hxz, s.mz, hxy * s.my);
+  const float hmy = fmaf(hyz, s.mz, hxy * s.mx);
+  const float hmz = fmaf(hyz, s.my, hxz * s.mx);
+  s.lx = fmaf(ds, fmaf(dn, gx, n * hmx), s.lx);
+  s.ly = fmaf(ds, fmaf(dn, gy, n * hmy), s.ly);
+  s.lz = fmaf(ds, fmaf(dn, gz, n * hmz), s.lz);
+  s.mx = fmaf(ds, s.lx, s.mx); s.my = fmaf(ds, s.ly, s.my); s.mz = fmaf(ds, s.lz, s.mz);   // :435
+  return true;
+}
+
+// ---- cylinder (radial profile) volume, src/cylinder_volume.cpp ---------------------------------
+struct Cyl {
+  const float* data;    // may point to LDS
+  int rres;
+  float radius, length;
+  float h, inv_h;       // h = radius/(rres-1) (:42), inv_h = 1/h
+  float r2;             // radius*radius
+};
+
+DRRT_HD Cyl make_cyl(const float* data, int rres, float radius, float length) {
+  Cyl C; C.data = data; C.rres = rres; C.radius = radius; C.length = length;
+  C.h = radius / (float)(rres - 1); C.inv_h = 1.f / C.h; C.r2 = radius * radius;
+  return C;
+}
+
+struct CylCell { int i0, i1; float w0, r, rhx, rhz; bool tiny; };
+
+DRRT_HD CylCell cyl_locate(const Cyl& C, float px, float pz) {
+  CylCell c;
+  float xs = px - C.radius, zs = pz - C.radius;                 // :37-38 (y component zeroed)
+  c.r = sqrtf(fmaf(xs, xs, zs * zs));                           // :41
+  float rm = c.r * C.inv_h;                                     // :44 (r / h)
+  int ir = f2i_sat(floorf(rm));
+  c.i0 = clampi(ir, 0, C.rres - 1);                             // :45
+  c.i1 = clampi(c.i0 + 1, 0, C.rres - 1);                       // :46
+  c.w0 = rm - (float)c.i0;                                      // :48 (uses the CLAMPED idx0)
+  c.tiny = c.r < 1e-6f;                                         // :15, :56
+  float inv_r = c.tiny ? 0.f : 1.f / c.r;
+  c.rhx = xs * inv_r; c.rhz = zs * inv_r;                       // normalize(xs), zeroed when tiny
+  return c;
+}
+
+// src/cylinder_volume.cpp:150-156
+DRRT_HD bool cyl_inbounds(const Cyl& C, float px, float py, float pz) {
+  float xs = px - C.radius, zs = pz - C.radius;
+  return (fmaf(xs, xs, zs * zs) < C.r2) & (py < C.length) & (py >= 0.f);
+}
+// src/cylinder_volume.cpp:158-170
+DRRT_HD bool cyl_escaped(const Cyl& C, float px, float py, float pz, float vx, float vy, float vz) {
+  float xs = px - C.radius, zs = pz - C.radius;
+  bool esc_len = ((py < 0.f) & (vy < 0.f)) | ((py > C.length) & (vy > 0.f));
+  bool out_r = fmaf(xs, xs, zs * zs) >= C.r2;
+  bool esc_r = fmaf(xs, vx, zs * vz) > 0.f;
+  return (out_r & esc_r) | esc_len;
+}
+
+// one forward cable iteration (src/tracer.cpp:351-373); target/best in aux0..3 like MODE 3
+DRRT_HD void cable_fwd_step(const Cyl& C, float ds, FwdState& s) {
+  CylCell c = cyl_locate(C, s.x, s.z);                                  // :351 (unmasked gather)
+  float v0 = C.data[c.i0], v1 = C.data[c.i1];
+  float f = fmaf(v1, c.w0, v0 * (1.f - c.w0));                          // :53
+  float rx = (v1 - v0) * C.inv_h;                                       // :54
+  float dsn = ds * f;
+  s.vx = fmaf(dsn, rx * c.rhx, s.vx); s.vz = fmaf(dsn, rx * c.rhz, s.vz);   // :353 (grad_y = 0)
+  s.x = fmaf(ds, s.vx, s.x); s.y = fmaf(ds, s.vy, s.y); s.z = fmaf(ds, s.vz, s.z);   // :354
+  float ex = s.x - s.aux0, ey = s.y - s.aux1, ez = s.z - s.aux2;
+  float cur = dot3(ex, ey, ez, ex, ey, ez);                             // :356
+  bool cur_inside = cyl_inbounds(C, s.x, s.y, s.z);
+  bool cross = s.inside & !cur_inside;
+  s.esc = s.esc | cross | cyl_escaped(C, s.x, s.y, s.z, s.vx, s.vy, s.vz);   // :361-362
+  if (cur < s.aux3) { s.xtx = s.x; s.xty = s.y; s.xtz = s.z; s.vtx = s.vx; s.vty = s.vy; s.vtz = s.vz; s.aux3 = cur; } // :365-367
+  s.inside = cur_inside;
+}
+
+// one adjoint cable iteration (src/tracer.cpp:547-562); contribution: a0 at i0, a1 at i1
+DRRT_HD bool cable_adj_step(const Cyl& C, float ds, AdjState& s, int& i0, int& i1, float& a0, float& a1) {
+  s.x = fmaf(-ds, s.vx, s.x); s.y = fmaf(-ds, s.vy, s.y); s.z = fmaf(-ds, s.vz, s.z);     // :547
+  CylCell c = cyl_locate(C, s.x, s.z);
+  float v0 = C.data[c.i0], v1 = C.data[c.i1];
+  float w0 = c.w0, w1 = 1.f - c.w0;
+  float n = fmaf(v1, w0, v0 * w1);                                      // :53
+  float rx = (v1 - v0) * C.inv_h;                                       // :54 / :88
+  float gx = rx * c.rhx, gz = rx * c.rhz;                               // grad n (y comp 0)
+  float mdsn = -ds * n;
+  s.vx = fmaf(mdsn, gx, s.vx); s.vz = fmaf(mdsn, gz, s.vz);             // :550
+  s.active = !cyl_escaped(C, s.x, s.y, s.z, -s.vx, -s.vy, -s.vz);       // :552
+  if (!s.active) return false;
+  float dn = fmaf(s.mz, gz, s.mx * gx);                                 // :557
+  // cylinder_volume::splat (:113-148): value taps val*w, gradient taps -+(grad.rhat)/h
+  float val = dn * ds;
+  float gv = (n * ds) * fmaf(s.mz, c.rhz, s.mx * c.rhx);                // dot(dnx*ds, rhat); 0 if tiny
+  float gvh = gv * C.inv_h;
+  i0 = c.i0; i1 = c.i1;
+  a0 = fmaf(val, w1, -gvh); a1 = fmaf(val, w0, gvh);
+  // Hessian (:88-108): (I - rhat rhat^T)_{xz} * (n'/r), zero when r < eps
+  float sH = c.tiny ? 0.f : rx / c.r;
+  float h00 = (1.f - c.rhx * c.rhx) * sH, h02 = -(c.rhx * c.rhz) * sH, h22 = (1.f - c.rhz * c.rhz) * sH;
+  float hmx = fmaf(h02, s.mz, h00 * s.mx), hmz = fmaf(h22, s.mz, h02 * s.mx);
+  s.lx = fmaf(ds, fmaf(dn, gx, n * hmx), s.lx);                         // :561 (y row of H is 0)
+  s.lz = fmaf(ds, fmaf(dn, gz, n * hmz), s.lz);
+  s.mx = fmaf(ds, s.lx, s.mx); s.my = fmaf(ds, s.ly, s.my); s.mz = fmaf(ds, s.lz, s.mz);   // :562
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// whole-ray drivers shared by the kernels (one ray per lane) and by tests/hostcheck
+// ---------------------------------------------------------------------------------------------
+struct RayOut { float xt[3], vt[3]; float dist2; bool esc, act; unsigned steps; };
+
+// trace / trace_plane / trace_sdf for ONE ray, per-ray termination (see drrt_kernels.hip header)
+template <int MODE>
+DRRT_HD RayOut trace_ray(const Vol& V, const float* __restrict__ sdf, float ds, int max_steps,
+                         const float p[3], const float v[3], const float* pln_o, const float* pln_d) {
+  FwdState s;
+  s.x = p[0]; s.y = p[1]; s.z = p[2]; s.vx = v[0]; s.vy = v[1]; s.vz = v[2];
+  s.aux0 = s.aux1 = s.aux2 = s.aux3 = s.aux4 = s.aux5 = 0.f;
+  if (MODE == 1) {
+    s.aux0 = pln_o[0]; s.aux1 = pln_o[1]; s.aux2 = pln_o[2];
+    s.aux3 = pln_d[0]; s.aux4 = pln_d[1]; s.aux5 = pln_d[2];
+  }
+  fwd_init(V, s);
+  bool act = true;
+  if (MODE == 2) {                                                        // src/tracer.cpp:276-277
+    Cell c = locate(V, s.x, s.y, s.z);
+    act = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n < 0.f;
+  }
+  unsigned steps = 0;
+  for (int it = 0; it < max_steps; ++it) {
+    fwd_step<MODE>(V, sdf, ds, s);
+    ++steps;
+    if (s.esc) break;                                                     // per-ray form of :82
+  }
+  act = act & !s.esc;                                                     // :77
+  if (MODE != 2 && !s.esc) { s.xtx = s.x; s.xty = s.y; s.xtz = s.z; }     // :95 (vt stays, Q6)
+  RayOut o;
+  o.xt[0] = s.xtx; o.xt[1] = s.xty; o.xt[2] = s.xtz; o.vt[0] = s.vtx; o.vt[1] = s.vty; o.vt[2] = s.vtz;
+  o.dist2 = 0.f; o.esc = s.esc; o.act = act; o.steps = steps;
+  return o;
+}
+
+// trace_target phase A for ONE ray: march until escaped, track the closest approach;
+// `cont` receives the marching state (x, v) for phase B.
+DRRT_HD RayOut target_ray_a(const Vol& V, float ds, int max_steps, const float p[3], const float v[3],
+                            const float tg[3], float cont[6]) {
+  FwdState s;
+  s.x = p[0]; s.y = p[1]; s.z = p[2]; s.vx = v[0]; s.vy = v[1]; s.vz = v[2];
+  s.aux0 = tg[0]; s.aux1 = tg[1]; s.aux2 = tg[2]; s.aux4 = s.aux5 = 0.f;
+  float ex = s.x - tg[0], ey = s.y - tg[1], ez = s.z - tg[2];
+  s.aux3 = dot3(ex, ey, ez, ex, ey, ez);                                  // src/tracer.cpp:200
+  fwd_init(V, s);
+  unsigned steps = 0;
+  for (int it = 0; it < max_steps; ++it) {
+    fwd_step<3>(V, nullptr, ds, s);
+    ++steps;
+    if (s.esc) break;
+  }
+  RayOut o;
+  o.xt[0] = s.xtx; o.xt[1] = s.xty; o.xt[2] = s.xtz; o.vt[0] = s.vtx; o.vt[1] = s.vty; o.vt[2] = s.vtz;
+  o.dist2 = s.aux3; o.esc = s.esc; o.act = !s.esc; o.steps = steps;
+  cont[0] = s.x; cont[1] = s.y; cont[2] = s.z; cont[3] = s.vx; cont[4] = s.vy; cont[5] = s.vz;
+  return o;
+}
+
+// trace_target phase B for ONE ray: an escaped ray flies straight (its gathers are masked) for
+// the remaining `total - done` iterations of the reference's global loop (:225-227 is not gated
+// by `escaped`).  Returns true when the closest-approach record was improved.
+DRRT_HD bool target_ray_b(float ds, unsigned done, unsigned total, const float cont[6], const float tg[3],
+                          float& best, float xt[3], float vt[3]) {
+  float x = cont[0], y = cont[1], z = cont[2];
+  const float vx = cont[3], vy = cont[4], vz = cont[5];
+  bool upd = false;
+  for (unsigned k = done; k < total; ++k) {
+    x = fmaf(ds, vx, x); y = fmaf(ds, vy, y); z = fmaf(ds, vz, z);
+    float ex = x - tg[0], ey = y - tg[1], ez = z - tg[2];
+    float cur = dot3(ex, ey, ez, ex, ey, ez);
+    if (cur < best) { best = cur; xt[0] = x; xt[1] = y; xt[2] = z; upd = true; }
+  }
+  if (upd) { vt[0] = vx; vt[1] = vy; vt[2] = vz; }
+  return upd;
+}
+
+// backtrace / backtrace_sdf for ONE ray; `sink(cell, corners)` receives every contribution.
+template <int MODE, typename Sink>
+DRRT_HD unsigned backtrace_ray(const Vol& V, const float* __restrict__ sdf, float ds, float grad_scale,
+                               int max_steps, const float xt[3], const float vt[3], const float dx[3],
+                               const float dv[3], Sink&& sink) {
+  AdjState s;
+  s.x = xt[0]; s.y = xt[1]; s.z = xt[2]; s.vx = vt[0]; s.vy = vt[1]; s.vz = vt[2];
+  adj_init(V, ds, dx[0], dx[1], dx[2], dv[0], dv[1], dv[2], s);
+  if (MODE == 1 && s.active) {                                            // src/tracer.cpp:476-477
+    Cell c = locate(V, s.x, s.y, s.z);
+    s.outside = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n >= 0.f;
+  }
+  unsigned steps = 0;
+  for (int it = 0; it < max_steps && s.active; ++it) {
+    Cell c; Corners w;
+    if (!adj_step<MODE>(V, sdf, ds, grad_scale, s, c, w)) break;
+    ++steps;
+    sink(c, w);
+  }
+  return steps;
+}
+
+// trace_cable for ONE ray (src/tracer.cpp:312-382)
+DRRT_HD RayOut cable_trace_ray(const Cyl& C, float ds, int max_steps, const float p[3], const float v[3],
+                               const float tg[3]) {
+  FwdState s;
+  s.x = p[0]; s.y = p[1]; s.z = p[2]; s.vx = v[0]; s.vy = v[1]; s.vz = v[2];
+  s.xtx = s.x; s.xty = s.y; s.xtz = s.z; s.vtx = s.vx; s.vty = s.vy; s.vtz = s.vz;
+  s.aux0 = tg[0]; s.aux1 = tg[1]; s.aux2 = tg[2]; s.aux4 = s.aux5 = 0.f;
+  float ex = s.x - tg[0], ey = s.y - tg[1], ez = s.z - tg[2];
+  s.aux3 = dot3(ex, ey, ez, ex, ey, ez);                                  // :340
+  s.inside = cyl_inbounds(C, s.x, s.y, s.z);                              // :344
+  s.esc = false;
+  unsigned steps = 0;
+  for (int it = 0; it < max_steps; ++it) {
+    cable_fwd_step(C, ds, s);
+    ++steps;
+    if (s.esc) break;          // state is frozen once !active (:353-354): nothing changes later
+  }
+  RayOut o;
+  o.xt[0] = s.xtx; o.xt[1] = s.xty; o.xt[2] = s.xtz; o.vt[0] = s.vtx; o.vt[1] = s.vty; o.vt[2] = s.vtz;
+  o.dist2 = s.aux3; o.esc = s.esc; o.act = !s.esc; o.steps = steps;
+  return o;
+}
+
+// backtrace_cable for ONE ray (src/tracer.cpp:511-567); sink(i0, i1, a0, a1)
+template <typename Sink>
+DRRT_HD unsigned cable_backtrace_ray(const Cyl& C, float ds, int max_steps, const float xt[3], const float vt[3],
+                                     const float dx[3], const float dv[3], Sink&& sink) {
+  AdjState s;
+  s.x = xt[0]; s.y = xt[1]; s.z = xt[2]; s.vx = vt[0]; s.vy = vt[1]; s.vz = vt[2];
+  s.lx = dx[0]; s.ly = dx[1]; s.lz = dx[2];                               // :536
+  s.mx = fmaf(ds, dx[0], dv[0]); s.my = fmaf(ds, dx[1], dv[1]); s.mz = fmaf(ds, dx[2], dv[2]);  // :537
+  s.active = !cyl_escaped(C, s.x, s.y, s.z, -s.vx, -s.vy, -s.vz);         // :540-541
+  s.outside = false;
+  unsigned steps = 0;
+  for (int it = 0; it < max_steps && s.active; ++it) {
+    int i0, i1; float a0, a1;
+    if (!cable_adj_step(C, ds, s, i0, i1, a0, a1)) break;
+    ++steps;
+    sink(i0, i1, a0, a1);
+  }
+  return steps;
+}
+
+#if defined(__HIPCC__)
 // fp32 atomic add without return: one global_atomic_add_f32 on gfx950 (no CAS loop).
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
@@ -142,46 +512,6 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor(v, o, kWave));
   return v;
 }
-
-// ---- cylinder (radial profile) volume, src/cylinder_volume.cpp ---------------------------------
-struct Cyl {
-  const float* data;    // may point to LDS
-  int rres;
-  float radius, length;
-  float h, inv_h;       // h = radius/(rres-1)  (:42)
-  float r2;             // radius^2
-};
-
-struct CylCell { int i0, i1; float w0, r, rhx, rhz; bool tiny; };
-
-__device__ __forceinline__ CylCell cyl_locate(const Cyl& C, float px, float pz) {
-  CylCell c;
-  float xs = px - C.radius, zs = pz - C.radius;                 // :37-38 (y component zeroed)
-  c.r = sqrtf(fmaf(xs, xs, zs * zs));                           // :41
-  float rm = c.r * C.inv_h;                                     // :44 (r / h)
-  int ir = (int)floorf(rm);
-  c.i0 = clampi(ir, 0, C.rres - 1);                             // :45
-  c.i1 = clampi(c.i0 + 1, 0, C.rres - 1);                       // :46
-  c.w0 = rm - (float)c.i0;                                      // :48 (uses the CLAMPED idx0)
-  c.tiny = c.r < 1e-6f;                                         // :15, :56
-  float inv_r = c.tiny ? 0.f : 1.f / c.r;
-  c.rhx = xs * inv_r; c.rhz = zs * inv_r;                       // normalize(xs), zeroed when tiny
-  return c;
-}
-
-// src/cylinder_volume.cpp:150-156
-__device__ __forceinline__ bool cyl_inbounds(const Cyl& C, float px, float py, float pz) {
-  float xs = px - C.radius, zs = pz - C.radius;
-  return ((xs * xs + zs * zs) < C.r2) & (py < C.length) & (py >= 0.f);
-}
-// src/cylinder_volume.cpp:158-170
-__device__ __forceinline__ bool cyl_escaped(const Cyl& C, float px, float py, float pz,
-                                            float vx, float vy, float vz) {
-  float xs = px - C.radius, zs = pz - C.radius;
-  bool esc_len = ((py < 0.f) & (vy < 0.f)) | ((py > C.length) & (vy > 0.f));
-  bool out_r = (xs * xs + zs * zs) >= C.r2;
-  bool esc_r = (xs * vx + zs * vz) > 0.f;
-  return (out_r & esc_r) | esc_len;
-}
+#endif
 
 }  // namespace drrt

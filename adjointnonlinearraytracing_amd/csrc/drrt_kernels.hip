@@ -78,62 +78,18 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
   unsigned steps = 0, failed = 0;
   if (t < a.n) {
     const size_t i = a.perm ? (size_t)a.perm[t] : t;
-    const Vol& V = a.vol;
     Ray3 p = ld3(a.pos, i), u = ld3(a.vel, i);
-    float x = p.x, y = p.y, z = p.z, vx = u.x, vy = u.y, vz = u.z;
-    float xtx = x, xty = y, xtz = z, vtx = vx, vty = vy, vtz = vz;          // :56-57
-    float pox = 0, poy = 0, poz = 0, pdx = 0, pdy = 0, pdz = 0;
+    const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
+    float po[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
     if (MODE == 1) {
       Ray3 o = ld3(a.pln_o, i), d = ld3(a.pln_d, i);
-      pox = o.x; poy = o.y; poz = o.z; pdx = d.x; pdy = d.y; pdz = d.z;
+      po[0] = o.x; po[1] = o.y; po[2] = o.z; pd[0] = d.x; pd[1] = d.y; pd[2] = d.z;
     }
-    bool inside = inbounds(V, x, y, z);                                    // :61
-    bool esc = false;                                                       // :62
-    bool act = true;
-    if (MODE == 2) {                                                        // :276-277
-      Cell c = locate(V, x, y, z);
-      Sample s = interp<false>(fetch(a.sdf, c), c.wx, c.wy, c.wz);
-      act = s.n < 0.f;
-    }
-    const float ds = a.ds, inv_h = V.inv_h;
-    for (int it = 0; it < a.max_steps; ++it) {
-      float n = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-      if (inside) {                                                         // masked gather (Q4)
-        Cell c = locate(V, x, y, z);
-        Sample s = interp<false>(fetch(V.data, c), c.wx, c.wy, c.wz);
-        n = s.n; gx = s.gx * inv_h; gy = s.gy * inv_h; gz = s.gz * inv_h;
-      }
-      const float dsn = ds * n;
-      vx = fmaf(dsn, gx, vx); vy = fmaf(dsn, gy, vy); vz = fmaf(dsn, gz, vz);     // :70
-      x = fmaf(ds, vx, x); y = fmaf(ds, vy, y); z = fmaf(ds, vz, z);               // :71
-      bool cur_inside;
-      if (MODE == 2) {                                                      // :287-288
-        float d = 0.f;
-        if (inside) {
-          Cell c = locate(V, x, y, z);
-          d = interp<false>(fetch(a.sdf, c), c.wx, c.wy, c.wz).n;
-        }
-        cur_inside = d < 0.f;
-      } else {
-        cur_inside = inbounds(V, x, y, z);                                  // :73
-        if (MODE == 1) {                                                    // :144-145
-          float dot = (x - pox) * pdx + (y - poy) * pdy + (z - poz) * pdz;
-          cur_inside = cur_inside & !(dot > 0.f);
-        }
-      }
-      const bool cross = inside & !cur_inside;                              // :74
-      esc = esc | cross | escaped(V, x, y, z, vx, vy, vz);                  // :75-76
-      if (cross) { xtx = x; xty = y; xtz = z; vtx = vx; vty = vy; vtz = vz; }  // :79-80
-      ++steps;
-      if (esc) break;                                                       // per-ray form of :82
-      inside = cur_inside;                                                  // :86
-    }
-    act = act & !esc;                                                       // :77
-    if (MODE != 2 && !esc) { xtx = x; xty = y; xtz = z; }                   // :95 (vt stays, Q6)
-    failed = act ? 1u : 0u;
-    st3(a.xt, i, xtx, xty, xtz);
-    st3(a.vt, i, vtx, vty, vtz);
-    if (MODE == 1) a.failmask[i] = esc ? 0 : 1;                             // :171
+    RayOut r = trace_ray<MODE>(a.vol, a.sdf, a.ds, a.max_steps, pp, vv, po, pd);
+    steps = r.steps; failed = r.act ? 1u : 0u;
+    st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2]);
+    st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2]);
+    if (MODE == 1) a.failmask[i] = r.esc ? 0 : 1;                           // src/tracer.cpp:171
   }
   block_stats(a.stats, steps, failed);
 }
@@ -159,41 +115,16 @@ __global__ void __launch_bounds__(kBlock) k_target_a(TargetArgs a) {
   unsigned steps = 0, failed = 0;
   if (t < a.n) {
     const size_t i = a.perm ? (size_t)a.perm[t] : t;
-    const Vol& V = a.vol;
     Ray3 p = ld3(a.pos, i), u = ld3(a.vel, i), tg = ld3(a.target, i);
-    float x = p.x, y = p.y, z = p.z, vx = u.x, vy = u.y, vz = u.z;
-    float xtx = x, xty = y, xtz = z, vtx = vx, vty = vy, vtz = vz;
-    float ex = x - tg.x, ey = y - tg.y, ez = z - tg.z;
-    float best = ex * ex + ey * ey + ez * ez;                               // :200
-    bool inside = inbounds(V, x, y, z);
-    bool esc = false;
-    const float ds = a.ds, inv_h = V.inv_h;
-    for (int it = 0; it < a.max_steps; ++it) {
-      float n = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-      if (inside) {
-        Cell c = locate(V, x, y, z);
-        Sample s = interp<false>(fetch(V.data, c), c.wx, c.wy, c.wz);
-        n = s.n; gx = s.gx * inv_h; gy = s.gy * inv_h; gz = s.gz * inv_h;
-      }
-      const float dsn = ds * n;
-      vx = fmaf(dsn, gx, vx); vy = fmaf(dsn, gy, vy); vz = fmaf(dsn, gz, vz);
-      x = fmaf(ds, vx, x); y = fmaf(ds, vy, y); z = fmaf(ds, vz, z);
-      ex = x - tg.x; ey = y - tg.y; ez = z - tg.z;
-      float cur = ex * ex + ey * ey + ez * ez;                              // :216
-      bool cur_inside = inbounds(V, x, y, z);
-      bool cross = inside & !cur_inside;
-      esc = esc | cross | escaped(V, x, y, z, vx, vy, vz);
-      if (cur < best) { xtx = x; xty = y; xtz = z; vtx = vx; vty = vy; vtz = vz; best = cur; } // :225-227
-      ++steps;
-      if (esc) break;
-      inside = cur_inside;
-    }
-    failed = esc ? 0u : 1u;
-    st3(a.xt, i, xtx, xty, xtz); st3(a.vt, i, vtx, vty, vtz); a.dist2[i] = best;
-    float* s = a.state;
-    s[0 * a.n + i] = x;  s[1 * a.n + i] = y;  s[2 * a.n + i] = z;
-    s[3 * a.n + i] = vx; s[4 * a.n + i] = vy; s[5 * a.n + i] = vz;
-    s[6 * a.n + i] = __uint_as_float(steps);
+    const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z}, tt[3] = {tg.x, tg.y, tg.z};
+    float cont[6];
+    RayOut r = target_ray_a(a.vol, a.ds, a.max_steps, pp, vv, tt, cont);
+    steps = r.steps; failed = r.esc ? 0u : 1u;
+    st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2]); st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2]); a.dist2[i] = r.dist2;
+    float* w = a.state;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k * a.n + i] = cont[k];
+    w[6 * a.n + i] = __uint_as_float(steps);
   }
   block_stats(a.stats, steps, failed);
 }
@@ -202,22 +133,18 @@ __global__ void __launch_bounds__(kBlock) k_target_b(TargetArgs a) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.n) return;
   const unsigned total = a.stats->iters;         // written by phase A (stream-ordered)
-  const float* s = a.state;
-  unsigned done = __float_as_uint(s[6 * a.n + i]);
+  const float* w = a.state;
+  const unsigned done = __float_as_uint(w[6 * a.n + i]);
   if (done >= total) return;
-  float x = s[0 * a.n + i], y = s[1 * a.n + i], z = s[2 * a.n + i];
-  const float vx = s[3 * a.n + i], vy = s[4 * a.n + i], vz = s[5 * a.n + i];
+  float cont[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cont[k] = w[k * a.n + i];
   Ray3 tg = ld3(a.target, i);
-  float best = a.dist2[i];
-  float bx = 0, by = 0, bz = 0; bool upd = false;
-  const float ds = a.ds;
-  for (unsigned k = done; k < total; ++k) {      // escaped ray: masked gathers => straight flight
-    x = fmaf(ds, vx, x); y = fmaf(ds, vy, y); z = fmaf(ds, vz, z);
-    float ex = x - tg.x, ey = y - tg.y, ez = z - tg.z;
-    float cur = ex * ex + ey * ey + ez * ez;
-    if (cur < best) { best = cur; bx = x; by = y; bz = z; upd = true; }
+  const float tt[3] = {tg.x, tg.y, tg.z};
+  float best = a.dist2[i], xt[3], vt[3];
+  if (target_ray_b(a.ds, done, total, cont, tt, best, xt, vt)) {
+    st3(a.xt, i, xt[0], xt[1], xt[2]); st3(a.vt, i, vt[0], vt[1], vt[2]); a.dist2[i] = best;
   }
-  if (upd) { st3(a.xt, i, bx, by, bz); st3(a.vt, i, vx, vy, vz); a.dist2[i] = best; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,49 +169,18 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
   unsigned steps = 0;
   if (t < a.n) {
     const size_t i = a.perm ? (size_t)a.perm[t] : t;
-    const Vol& V = a.vol;
     Ray3 p = ld3(a.xt, i), u = ld3(a.vt, i), gxv = ld3(a.dx, i), gvv = ld3(a.dv, i);
-    float x = p.x, y = p.y, z = p.z, vx = u.x, vy = u.y, vz = u.z;
-    const float ds = a.ds, inv_h = V.inv_h, inv_h2 = inv_h * inv_h;
-    float lx = gxv.x, ly = gxv.y, lz = gxv.z;                               // :409
-    float mx = fmaf(ds, gxv.x, gvv.x), my = fmaf(ds, gxv.y, gvv.y), mz = fmaf(ds, gxv.z, gvv.z); // :410
-    bool active = !escaped(V, x, y, z, -vx, -vy, -vz);                      // :413-414
-    bool outside = false;
-    if (MODE == 1 && active) {                                              // :476-477
-      Cell c = locate(V, x, y, z);
-      outside = interp<false>(fetch(a.sdf, c), c.wx, c.wy, c.wz).n >= 0.f;
-    }
-    for (int it = 0; it < a.max_steps && active; ++it) {
-      x = fmaf(-ds, vx, x); y = fmaf(-ds, vy, y); z = fmaf(-ds, vz, z);     // :420
-      Cell c = locate(V, x, y, z);
-      Sample s = interp<true>(fetch(V.data, c), c.wx, c.wy, c.wz);          // :421-422 (one fetch)
-      const float n = s.n, gx = s.gx * inv_h, gy = s.gy * inv_h, gz = s.gz * inv_h;
-      const float mdsn = -ds * n;
-      vx = fmaf(mdsn, gx, vx); vy = fmaf(mdsn, gy, vy); vz = fmaf(mdsn, gz, vz);   // :423
-      active = !escaped(V, x, y, z, -vx, -vy, -vz);                         // :425
-      if (MODE == 1) {                                                      // :488-497
-        bool now_out = interp<false>(fetch(a.sdf, c), c.wx, c.wy, c.wz).n >= 0.f;
-        active = active & !((!outside) & now_out);
-        outside = now_out;
-      }
-      if (!active) break;                                                   // :426-428
-      ++steps;
-      const float dn = mx * gx + my * gy + mz * gz;                         // :430
-      const float nds = n * ds * a.grad_scale;
-      Corners w = splat_weights(c.wx, c.wy, c.wz, dn * ds, nds * mx, nds * my, nds * mz); // :431-432
-      float* g = a.grad + c.base;
-      atomic_add_f32(g, w.c000);                    atomic_add_f32(g + c.ox, w.c100);
-      atomic_add_f32(g + c.oy, w.c010);             atomic_add_f32(g + c.oy + c.ox, w.c110);
-      atomic_add_f32(g + c.oz, w.c001);             atomic_add_f32(g + c.oz + c.ox, w.c101);
-      atomic_add_f32(g + c.oz + c.oy, w.c011);      atomic_add_f32(g + c.oz + c.oy + c.ox, w.c111);
-      // la += ds*(dn*grad n + n*H*mu), H = mixed partials / h^2 with zero diagonal (:434, Q10)
-      const float hxy = s.hxy * inv_h2, hxz = s.hxz * inv_h2, hyz = s.hyz * inv_h2;
-      const float hmx = hxy * my + hxz * mz, hmy = hxy * mx + hyz * mz, hmz = hxz * mx + hyz * my;
-      lx = fmaf(ds, fmaf(dn, gx, n * hmx), lx);
-      ly = fmaf(ds, fmaf(dn, gy, n * hmy), ly);
-      lz = fmaf(ds, fmaf(dn, gz, n * hmz), lz);
-      mx = fmaf(ds, lx, mx); my = fmaf(ds, ly, my); mz = fmaf(ds, lz, mz);  // :435
-    }
+    const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
+    const float dxx[3] = {gxv.x, gxv.y, gxv.z}, dvv[3] = {gvv.x, gvv.y, gvv.z};
+    float* grad = a.grad;
+    steps = backtrace_ray<MODE>(a.vol, a.sdf, a.ds, a.grad_scale, a.max_steps, pp, vv, dxx, dvv,
+      [grad](const Cell& c, const Corners& w) {
+        float* g = grad + c.base;
+        atomic_add_f32(g, w.c000);                    atomic_add_f32(g + c.ox, w.c100);
+        atomic_add_f32(g + c.oy, w.c010);             atomic_add_f32(g + c.oy + c.ox, w.c110);
+        atomic_add_f32(g + c.oz, w.c001);             atomic_add_f32(g + c.oz + c.ox, w.c101);
+        atomic_add_f32(g + c.oz + c.oy, w.c011);      atomic_add_f32(g + c.oz + c.oy + c.ox, w.c111);
+      });
   }
   block_stats(a.stats, steps, 0u);
 }
@@ -306,10 +202,14 @@ struct CableArgs {
   size_t n;
 };
 
-__device__ __forceinline__ Cyl make_cyl(const CableArgs& a, const float* data) {
-  Cyl C; C.data = data; C.rres = a.rres; C.radius = a.radius; C.length = a.length;
-  C.h = a.radius / (float)(a.rres - 1); C.inv_h = 1.f / C.h; C.r2 = a.radius * a.radius;
-  return C;
+__device__ __forceinline__ void cable_stats(drrt_stats* stats, unsigned steps_tot, unsigned steps_max, unsigned fail_tot) {
+  if (!stats) return;
+  unsigned wm = wave_max_u32(steps_max), ws = wave_sum_u32(steps_tot), wf = wave_sum_u32(fail_tot);
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    if (wm) atomicMax(&stats->iters, wm);
+    if (ws) atomicAdd(&stats->ray_steps, (unsigned long long)ws);
+    if (wf) atomicAdd(&stats->n_failed, (unsigned long long)wf);
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) k_trace_cable(CableArgs a) {
@@ -319,48 +219,16 @@ __global__ void __launch_bounds__(kBlock) k_trace_cable(CableArgs a) {
     for (int k = threadIdx.x; k < a.rres; k += kBlock) s_prof[k] = a.rif[k];
     __syncthreads();
   }
-  const Cyl C = make_cyl(a, use_lds ? s_prof : a.rif);
+  const Cyl C = make_cyl(use_lds ? s_prof : a.rif, a.rres, a.radius, a.length);
   unsigned steps_tot = 0, fail_tot = 0, steps_max = 0;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (size_t)gridDim.x * kBlock) {
     Ray3 p = ld3(a.pos, i), u = ld3(a.vel, i), tg = ld3(a.target, i);
-    float x = p.x, y = p.y, z = p.z, vx = u.x, vy = u.y, vz = u.z;
-    float xtx = x, xty = y, xtz = z, vtx = vx, vty = vy, vtz = vz;
-    float ex = x - tg.x, ey = y - tg.y, ez = z - tg.z;
-    float best = ex * ex + ey * ey + ez * ez;                               // :340
-    bool inside = cyl_inbounds(C, x, y, z);                                 // :344
-    bool esc = false;
-    unsigned steps = 0;
-    for (int it = 0; it < a.max_steps; ++it) {
-      CylCell c = cyl_locate(C, x, z);                                      // :351 (unmasked gather)
-      float v0 = C.data[c.i0], v1 = C.data[c.i1];
-      float f = v0 * (1.f - c.w0) + v1 * c.w0;                              // :53
-      float rx = (v1 - v0) * C.inv_h;                                       // :54
-      float dsn = a.ds * f;
-      vx = fmaf(dsn, rx * c.rhx, vx); vz = fmaf(dsn, rx * c.rhz, vz);       // :353 (y comp of grad = 0)
-      x = fmaf(a.ds, vx, x); y = fmaf(a.ds, vy, y); z = fmaf(a.ds, vz, z);  // :354
-      ex = x - tg.x; ey = y - tg.y; ez = z - tg.z;
-      float cur = ex * ex + ey * ey + ez * ez;                              // :356
-      bool cur_inside = cyl_inbounds(C, x, y, z);
-      bool cross = inside & !cur_inside;
-      esc = esc | cross | cyl_escaped(C, x, y, z, vx, vy, vz);              // :361-362
-      if (cur < best) { xtx = x; xty = y; xtz = z; vtx = vx; vty = vy; vtz = vz; best = cur; } // :365-367
-      ++steps;
-      if (esc) break;          // state is frozen once !active (:353-354), so nothing changes later
-      inside = cur_inside;
-    }
-    st3(a.xt, i, xtx, xty, xtz); st3(a.vt, i, vtx, vty, vtz); a.dist2[i] = best;
-    steps_tot += steps; steps_max = max(steps_max, steps); fail_tot += esc ? 0u : 1u;
+    const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z}, tt[3] = {tg.x, tg.y, tg.z};
+    RayOut r = cable_trace_ray(C, a.ds, a.max_steps, pp, vv, tt);
+    st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2]); st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2]); a.dist2[i] = r.dist2;
+    steps_tot += r.steps; steps_max = max(steps_max, r.steps); fail_tot += r.esc ? 0u : 1u;
   }
-  // block_stats takes (sum, fail) per thread and a max of the same quantity; feed the max separately
-  if (a.stats) {
-    unsigned wm = wave_max_u32(steps_max);
-    if ((threadIdx.x & (kWave - 1)) == 0 && wm) atomicMax(&a.stats->iters, wm);
-    unsigned ws = wave_sum_u32(steps_tot), wf = wave_sum_u32(fail_tot);
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-      if (ws) atomicAdd(&a.stats->ray_steps, (unsigned long long)ws);
-      if (wf) atomicAdd(&a.stats->n_failed, (unsigned long long)wf);
-    }
-  }
+  cable_stats(a.stats, steps_tot, steps_max, fail_tot);
 }
 
 __global__ void __launch_bounds__(kBlock) k_backtrace_cable(CableArgs a) {
@@ -372,45 +240,18 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_cable(CableArgs a) {
     for (int k = threadIdx.x; k < a.rres; k += kBlock) { s_prof[k] = a.rif[k]; s_grad[k] = 0.f; }
     __syncthreads();
   }
-  const Cyl C = make_cyl(a, use_lds ? s_prof : a.rif);
+  const Cyl C = make_cyl(use_lds ? s_prof : a.rif, a.rres, a.radius, a.length);
   float* acc = use_lds ? s_grad : a.grad;
   unsigned steps_tot = 0, steps_max = 0;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (size_t)gridDim.x * kBlock) {
     Ray3 p = ld3(a.pos, i), u = ld3(a.vel, i), gxv = ld3(a.dx, i), gvv = ld3(a.dv, i);
-    float x = p.x, y = p.y, z = p.z, vx = u.x, vy = u.y, vz = u.z;
-    const float ds = a.ds;
-    float lx = gxv.x, ly = gxv.y, lz = gxv.z;                               // :536
-    float mx = fmaf(ds, gxv.x, gvv.x), my = fmaf(ds, gxv.y, gvv.y), mz = fmaf(ds, gxv.z, gvv.z); // :537
-    bool active = !cyl_escaped(C, x, y, z, -vx, -vy, -vz);                  // :540-541
-    unsigned steps = 0;
-    for (int it = 0; it < a.max_steps && active; ++it) {
-      x = fmaf(-ds, vx, x); y = fmaf(-ds, vy, y); z = fmaf(-ds, vz, z);     // :547
-      CylCell c = cyl_locate(C, x, z);
-      float v0 = C.data[c.i0], v1 = C.data[c.i1];
-      float w0 = c.w0, w1 = 1.f - c.w0;
-      float n = v0 * w1 + v1 * w0;                                          // :53
-      float rx = (v1 - v0) * C.inv_h;                                       // :54 / :88
-      float gx = rx * c.rhx, gz = rx * c.rhz;                               // grad n (y comp 0)
-      float mdsn = -ds * n;
-      vx = fmaf(mdsn, gx, vx); vz = fmaf(mdsn, gz, vz);                     // :550
-      active = !cyl_escaped(C, x, y, z, -vx, -vy, -vz);                     // :552
-      if (!active) break;
-      ++steps;
-      float dn = mx * gx + mz * gz;                                         // :557
-      // cylinder_volume::splat (:113-148): value taps val*w, gradient taps -+(grad.rhat)/h
-      float val = dn * ds;
-      float gv = (n * ds) * (mx * c.rhx + mz * c.rhz);                      // dot(dnx*ds, rhat), 0 if tiny
-      float a0 = fmaf(val, w1, -gv * C.inv_h), a1 = fmaf(val, w0, gv * C.inv_h);
-      if (use_lds) { atomicAdd(&acc[c.i0], a0); atomicAdd(&acc[c.i1], a1); }
-      else { atomic_add_f32(&acc[c.i0], a0); atomic_add_f32(&acc[c.i1], a1); }
-      // Hessian (:88-108): (I - rhat rhat^T)_{xz} * (n'/r), zero when r < eps
-      float sH = c.tiny ? 0.f : rx / c.r;
-      float h00 = (1.f - c.rhx * c.rhx) * sH, h02 = -(c.rhx * c.rhz) * sH, h22 = (1.f - c.rhz * c.rhz) * sH;
-      float hmx = h00 * mx + h02 * mz, hmz = h02 * mx + h22 * mz;
-      lx = fmaf(ds, fmaf(dn, gx, n * hmx), lx);                             // :561
-      lz = fmaf(ds, fmaf(dn, gz, n * hmz), lz);
-      mx = fmaf(ds, lx, mx); my = fmaf(ds, ly, my); mz = fmaf(ds, lz, mz);  // :562
-    }
+    const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
+    const float dxx[3] = {gxv.x, gxv.y, gxv.z}, dvv[3] = {gvv.x, gvv.y, gvv.z};
+    unsigned steps = cable_backtrace_ray(C, a.ds, a.max_steps, pp, vv, dxx, dvv,
+      [acc, use_lds](int i0, int i1, float a0, float a1) {
+        if (use_lds) { atomicAdd(&acc[i0], a0); atomicAdd(&acc[i1], a1); }      // ds_add_f32
+        else { atomic_add_f32(&acc[i0], a0); atomic_add_f32(&acc[i1], a1); }
+      });
     steps_tot += steps; steps_max = max(steps_max, steps);
   }
   if (use_lds) {
@@ -420,14 +261,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_cable(CableArgs a) {
       if (g != 0.f) atomic_add_f32(&a.grad[k], g);
     }
   }
-  if (a.stats) {
-    unsigned wm = wave_max_u32(steps_max);
-    unsigned ws = wave_sum_u32(steps_tot);
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-      if (wm) atomicMax(&a.stats->iters, wm);
-      if (ws) atomicAdd(&a.stats->ray_steps, (unsigned long long)ws);
-    }
-  }
+  cable_stats(a.stats, steps_tot, steps_max, 0u);
 }
 
 }  // namespace drrt
@@ -457,6 +291,55 @@ static int fail_hip(hipError_t e, const char* where) {
 }
 
 extern "C" const char* drrt_last_error(void) { return g_err; }
+
+// ---- optional per-kernel timing (bench / profiling aid; not thread-safe) --------------------
+// Event pairs are recorded on the call's stream right around a kernel launch; nothing
+// synchronises until drrt_profile_collect().
+struct ProfRec { hipEvent_t a, b; int id; };
+static ProfRec* g_prof = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+
+struct ProfScope {
+  int slot; hipStream_t s;
+  ProfScope(int id, hipStream_t st) : slot(-1), s(st) {
+    if (g_prof && g_prof_n < g_prof_cap) {
+      slot = g_prof_n++;
+      g_prof[slot].id = id;
+      (void)hipEventRecord(g_prof[slot].a, s);
+    }
+  }
+  ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, s); }
+};
+
+extern "C" void drrt_profile_end(void) {
+  for (int i = 0; i < g_prof_cap; ++i) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
+  delete[] g_prof; g_prof = nullptr; g_prof_cap = g_prof_n = 0;
+}
+
+extern "C" int drrt_profile_begin(int capacity) {
+  drrt_profile_end();
+  if (capacity <= 0) return DRRT_OK;
+  g_prof = new ProfRec[capacity];
+  for (int i = 0; i < capacity; ++i) {
+    hipError_t e = hipEventCreate(&g_prof[i].a);
+    if (e == hipSuccess) e = hipEventCreate(&g_prof[i].b);
+    if (e != hipSuccess) { g_prof_cap = i; drrt_profile_end(); return fail_hip(e, "hipEventCreate"); }
+  }
+  g_prof_cap = capacity; g_prof_n = 0;
+  return DRRT_OK;
+}
+
+extern "C" int drrt_profile_collect(int* ids, float* ms, int max_out) {
+  int n = g_prof_n < max_out ? g_prof_n : max_out;
+  for (int i = 0; i < n; ++i) {
+    (void)hipEventSynchronize(g_prof[i].b);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+    ids[i] = g_prof[i].id; ms[i] = t;
+  }
+  g_prof_n = 0;
+  return n;
+}
 extern "C" const char* drrt_version(void) { return "drrt_hip 0.1 gfx950"; }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -478,7 +361,7 @@ static int make_vol(const float* rif, long long nvox, const int res[3], float h,
   if (nvox > 0x7fffffffLL) return fail(DRRT_ERR_ARG, "grid too large for int32 indexing");
   V->data = rif; V->W = res[0]; V->H = res[1]; V->D = res[2];
   V->sy = res[0]; V->sz = res[0] * res[1];
-  V->inv_h = 1.0f / h;
+  V->inv_h = 1.0f / h; V->inv_h2 = V->inv_h * V->inv_h;
   V->bx = (float)(res[0] - 1) * h; V->by = (float)(res[1] - 1) * h; V->bz = (float)(res[2] - 1) * h;
   return DRRT_OK;
 }
@@ -501,6 +384,7 @@ static int maybe_sort(const Vol& V, float h, size_t n, const float* pos, const f
   *perm = nullptr;
   if (!(flags & DRRT_FLAG_SORT_RAYS) || n < 2) return DRRT_OK;
   if (!ws || ws_bytes < sort_workspace_bytes(n)) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_SORT_RAYS");
+  ProfScope prof(DRRT_PROF_SORT, s);
   hipError_t e = sort_rays_by_entry_voxel(V, h, n, pos, vel, dir_sign, ws, ws_bytes, perm, s);
   return e == hipSuccess ? DRRT_OK : fail_hip(e, "sort_rays_by_entry_voxel");
 }
@@ -529,7 +413,10 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
   a.sdf = sdf; a.pos = pos; a.vel = vel; a.pln_o = pln_o; a.pln_d = pln_d;
   a.xt = xt; a.vt = vt; a.failmask = failmask; a.stats = stats; a.n = n; a.ds = ds;
   a.max_steps = (MODE == 2) ? steps_sdf(h, res, ds) : steps_fwd(h, res, ds);
-  hipLaunchKernelGGL(k_trace<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+  {
+    ProfScope prof(DRRT_PROF_TRACE, s);
+    hipLaunchKernelGGL(k_trace<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+  }
   LAUNCH_CHECK("k_trace");
   return DRRT_OK;
 }
@@ -599,6 +486,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   if (!grad) return fail(DRRT_ERR_ARG, "null grad pointer");
   if (MODE == 1 && !sdf) return fail(DRRT_ERR_ARG, "null sdf pointer");
   if (!(flags & DRRT_FLAG_NO_ZERO)) {                                        // src/tracer.cpp:401-403
+    ProfScope prof(DRRT_PROF_ZERO, s);
     hipError_t e = hipMemsetAsync(grad, 0, (size_t)nvox * sizeof(float), s);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(grad)");
   }
@@ -610,7 +498,10 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   a.sdf = sdf; a.xt = xt; a.vt = vt; a.dx = dx; a.dv = dv; a.grad = grad; a.stats = stats;
   a.n = n; a.ds = ds; a.max_steps = steps_adj(h, res, ds);
   a.grad_scale = (flags & DRRT_FLAG_CORRECTED_H) ? a.vol.inv_h : 1.0f;
-  hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+  {
+    ProfScope prof(DRRT_PROF_BACKTRACE, s);
+    hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+  }
   LAUNCH_CHECK("k_backtrace");
   return DRRT_OK;
 }

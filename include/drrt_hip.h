@@ -142,6 +142,19 @@ DRRT_API int drrt_backtrace_cable_f32(const float* rif, size_t rres, float radiu
                              drrt_stats* stats, void* workspace, size_t workspace_bytes,
                              unsigned flags, void* stream);
 
+/* ---- profiling aid (bench.py; no counterpart in the reference) --------------------------------
+ * After drrt_profile_begin(capacity) every march call records a HIP event pair on its stream
+ * around each kernel it launches (no synchronisation).  drrt_profile_collect() waits for the
+ * recorded events, writes up to max_out (kernel id, milliseconds) pairs in launch order, resets
+ * the log and returns the count.  Single-threaded use only.                                    */
+#define DRRT_PROF_TRACE      1   /* forward march kernel                 */
+#define DRRT_PROF_BACKTRACE  2   /* adjoint march kernel                 */
+#define DRRT_PROF_SORT       3   /* entry-voxel keys + radix sort        */
+#define DRRT_PROF_ZERO       4   /* zero-fill of the gradient grid       */
+DRRT_API int  drrt_profile_begin(int capacity);
+DRRT_API int  drrt_profile_collect(int* kernel_ids, float* ms, int max_out);
+DRRT_API void drrt_profile_end(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,10 +51,18 @@
 
 #define EXPORT __attribute__((visibility("default")))
 
+/* arithmetic mode: 0 = literal (the reference's expression order), 1 = factored (the explicit
+ * IEEE sequence the HIP kernels implement; see the second half of drrt_oracle_impl.h) */
+static int g_arith = 0;
+EXPORT void oracle_set_arith(int mode) { g_arith = mode ? 1 : 0; }
+EXPORT int oracle_get_arith(void) { return g_arith; }
+
 #define DEFINE_API(REAL, SFX)                                                                  \
 EXPORT int oracle_trace_##SFX(const REAL* rif, const int* res, long long nvox, size_t n,       \
     const REAL* pos, const REAL* vel, REAL h, REAL ds, REAL* xt, REAL* vt,                     \
     int* steps_out, long long* n_failed, int* iters) {                                         \
+  if (g_arith) return trace_fact_##SFX(0, rif, NULL, res, nvox, n, pos, vel, NULL, NULL, h, ds,\
+                                       xt, vt, NULL, NULL, steps_out, n_failed, iters);        \
   return trace_generic_##SFX(0, rif, NULL, res, nvox, n, pos, vel, NULL, NULL, h, ds, xt, vt,  \
                              NULL, steps_out, n_failed, iters);                                \
 }                                                                                              \
@@ -62,42 +70,56 @@ EXPORT int oracle_trace_pln_##SFX(const REAL* rif, const int* res, long long nvo
     const REAL* pos, const REAL* vel, const REAL* pln_o, const REAL* pln_d, REAL h, REAL ds,   \
     REAL* xt, REAL* vt, unsigned char* failmask, int* steps_out, long long* n_failed,          \
     int* iters) {                                                                              \
+  if (g_arith) return trace_fact_##SFX(1, rif, NULL, res, nvox, n, pos, vel, pln_o, pln_d, h,  \
+                                       ds, xt, vt, NULL, failmask, steps_out, n_failed, iters);\
   return trace_generic_##SFX(1, rif, NULL, res, nvox, n, pos, vel, pln_o, pln_d, h, ds, xt, vt,\
                              failmask, steps_out, n_failed, iters);                            \
 }                                                                                              \
 EXPORT int oracle_trace_sdf_##SFX(const REAL* rif, const REAL* sdf, const int* res,            \
     long long nvox, size_t n, const REAL* pos, const REAL* vel, REAL h, REAL ds,               \
     REAL* xt, REAL* vt, int* steps_out, long long* n_failed, int* iters) {                     \
+  if (g_arith) return trace_fact_##SFX(2, rif, sdf, res, nvox, n, pos, vel, NULL, NULL, h, ds, \
+                                       xt, vt, NULL, NULL, steps_out, n_failed, iters);        \
   return trace_generic_##SFX(2, rif, sdf, res, nvox, n, pos, vel, NULL, NULL, h, ds, xt, vt,   \
                              NULL, steps_out, n_failed, iters);                                \
 }                                                                                              \
 EXPORT int oracle_trace_target_##SFX(const REAL* rif, const int* res, long long nvox, size_t n,\
     const REAL* pos, const REAL* vel, const REAL* target, REAL h, REAL ds,                     \
     REAL* xt, REAL* vt, REAL* dist2, long long* n_failed, int* iters) {                        \
+  if (g_arith) return trace_fact_##SFX(3, rif, NULL, res, nvox, n, pos, vel, target, NULL, h,  \
+                                       ds, xt, vt, dist2, NULL, NULL, n_failed, iters);        \
   return trace_target_impl_##SFX(rif, res, nvox, n, pos, vel, target, h, ds, xt, vt, dist2,    \
                                  n_failed, iters);                                             \
 }                                                                                              \
 EXPORT int oracle_trace_cable_##SFX(const REAL* rif, size_t rres, REAL radius, REAL length,    \
     size_t n, const REAL* pos, const REAL* vel, const REAL* target, REAL ds,                   \
     REAL* xt, REAL* vt, REAL* dist2, long long* n_failed, long long* steps_total) {            \
+  if (g_arith) return trace_cable_fact_##SFX(rif, rres, radius, length, n, pos, vel, target,   \
+                                             ds, xt, vt, dist2, n_failed, steps_total);        \
   return trace_cable_impl_##SFX(rif, rres, radius, length, n, pos, vel, target, ds, xt, vt,    \
                                 dist2, n_failed, steps_total);                                 \
 }                                                                                              \
 EXPORT int oracle_backtrace_##SFX(const REAL* rif, const int* res, long long nvox, size_t n,   \
     const REAL* xt, const REAL* vt, const REAL* dx, const REAL* dv, REAL h, REAL ds,           \
     REAL grad_scale, REAL* grad, long long* steps_total) {                                     \
+  if (g_arith) return backtrace_fact_##SFX(0, rif, NULL, res, nvox, n, xt, vt, dx, dv, h, ds,  \
+                                           grad_scale, grad, steps_total);                     \
   return backtrace_generic_##SFX(0, rif, NULL, res, nvox, n, xt, vt, dx, dv, h, ds,            \
                                  grad_scale, grad, steps_total);                               \
 }                                                                                              \
 EXPORT int oracle_backtrace_sdf_##SFX(const REAL* rif, const REAL* sdf, const int* res,        \
     long long nvox, size_t n, const REAL* xt, const REAL* vt, const REAL* dx, const REAL* dv,  \
     REAL h, REAL ds, REAL grad_scale, REAL* grad, long long* steps_total) {                    \
+  if (g_arith) return backtrace_fact_##SFX(1, rif, sdf, res, nvox, n, xt, vt, dx, dv, h, ds,   \
+                                           grad_scale, grad, steps_total);                     \
   return backtrace_generic_##SFX(1, rif, sdf, res, nvox, n, xt, vt, dx, dv, h, ds,             \
                                  grad_scale, grad, steps_total);                               \
 }                                                                                              \
 EXPORT int oracle_backtrace_cable_##SFX(const REAL* rif, size_t rres, REAL radius, REAL length,\
     size_t n, const REAL* xt, const REAL* vt, const REAL* dx, const REAL* dv, REAL ds,         \
     REAL* grad, long long* steps_total) {                                                      \
+  if (g_arith) return backtrace_cable_fact_##SFX(rif, rres, radius, length, n, xt, vt, dx, dv, \
+                                                 ds, grad, steps_total);                       \
   return backtrace_cable_impl_##SFX(rif, rres, radius, length, n, xt, vt, dx, dv, ds, grad,    \
                                     steps_total);                                              \
 }                                                                                              \

@@ -532,3 +532,377 @@ static int FN(backtrace_cable_impl)(const REAL* rif, size_t rres, REAL radius, R
   if (steps_total) *steps_total = steps;
   return 0;
 }
+
+/* ================================================================================== */
+/* "factored" arithmetic mode                                                           */
+/*                                                                                      */
+/* Same algorithm, re-associated: n, grad n and the mixed partials come from one lerp   */
+/* tree (differences first) and volume::splat's 16 scatter_adds are fused into 8 corner */
+/* sums.  This is the explicit IEEE operation sequence that the HIP kernels implement   */
+/* (adjointnonlinearraytracing_amd/csrc/drrt_device.h, "ARITHMETIC CONTRACT"), restated  */
+/* here independently in plain C so that GPU trajectories can be compared bit for bit.   */
+/* It is validated against the literal mode above in float64 by tests/test_oracle.py     */
+/* (agreement ~1e-12), so the chain is: reference text == literal mode ~ factored mode   */
+/* == GPU.  The loops keep the reference's array-at-a-time structure and global breaks.  */
+/* ================================================================================== */
+
+typedef struct {
+  const REAL* data; int W, H, D, sy, sz; REAL inv_h, inv_h2, bx, by, bz;
+} FN(fvol_t);
+
+typedef struct { int base, ox, oy, oz; REAL wx, wy, wz; } FN(fcell_t);
+typedef struct { REAL n, gx, gy, gz, hxy, hxz, hyz; } FN(fsample_t);
+
+static inline void FN(fvol_make)(FN(fvol_t)* V, const REAL* data, const int res[3], REAL h) {
+  V->data = data; V->W = res[0]; V->H = res[1]; V->D = res[2]; V->sy = res[0]; V->sz = res[0]*res[1];
+  V->inv_h = (REAL)1 / h; V->inv_h2 = V->inv_h * V->inv_h;
+  V->bx = (REAL)(res[0]-1) * h; V->by = (REAL)(res[1]-1) * h; V->bz = (REAL)(res[2]-1) * h;
+}
+
+static inline int FN(f2i_sat)(REAL f) {
+  if (!(f == f)) return 0;
+  if (f >= (REAL)2147483648.0) return 2147483647;
+  if (f <= (REAL)-2147483648.0) return (-2147483647 - 1);
+  return (int)f;
+}
+
+static inline FN(fcell_t) FN(flocate)(const FN(fvol_t)* V, REAL px, REAL py, REAL pz) {
+  FN(fcell_t) c;
+  REAL fx = px * V->inv_h, fy = py * V->inv_h, fz = pz * V->inv_h;
+  REAL flx = FLOOR(fx), fly = FLOOR(fy), flz = FLOOR(fz);
+  c.wx = fx - flx; c.wy = fy - fly; c.wz = fz - flz;
+  int ix = FN(f2i_sat)(flx), iy = FN(f2i_sat)(fly), iz = FN(f2i_sat)(flz);
+  int x0 = FN(clampi)(ix, 0, V->W-1), x1 = FN(clampi)(ix+1, 0, V->W-1);
+  int y0 = FN(clampi)(iy, 0, V->H-1), y1 = FN(clampi)(iy+1, 0, V->H-1);
+  int z0 = FN(clampi)(iz, 0, V->D-1), z1 = FN(clampi)(iz+1, 0, V->D-1);
+  c.base = z0*V->sz + y0*V->sy + x0;
+  c.ox = x1 - x0; c.oy = (y1 - y0)*V->sy; c.oz = (z1 - z0)*V->sz;
+  return c;
+}
+
+static inline FN(fsample_t) FN(finterp)(const REAL* d, const FN(fcell_t)* c) {
+  const REAL* p = d + c->base;
+  REAL v000 = p[0], v100 = p[c->ox], v010 = p[c->oy], v110 = p[c->oy + c->ox];
+  REAL v001 = p[c->oz], v101 = p[c->oz + c->ox], v011 = p[c->oz + c->oy], v111 = p[c->oz + c->oy + c->ox];
+  REAL wx = c->wx, wy = c->wy, wz = c->wz;
+  FN(fsample_t) s;
+  REAL d00 = v100 - v000, d10 = v110 - v010, d01 = v101 - v001, d11 = v111 - v011;
+  REAL c00 = FMA(wx, d00, v000), c10 = FMA(wx, d10, v010);
+  REAL c01 = FMA(wx, d01, v001), c11 = FMA(wx, d11, v011);
+  REAL e0 = c10 - c00, e1 = c11 - c01;
+  REAL l0 = FMA(wy, e0, c00), l1 = FMA(wy, e1, c01);
+  REAL dz = l1 - l0;
+  s.gz = dz;
+  s.n = FMA(wz, dz, l0);
+  REAL eyz = e1 - e0;
+  s.gy = FMA(wz, eyz, e0);
+  REAL dxy0 = d10 - d00, dxy1 = d11 - d01;
+  REAL gx0 = FMA(wy, dxy0, d00), gx1 = FMA(wy, dxy1, d01);
+  REAL gxz = gx1 - gx0;
+  s.gx = FMA(wz, gxz, gx0);
+  s.hxy = FMA(wz, dxy1 - dxy0, dxy0);
+  s.hxz = gxz;
+  s.hyz = eyz;
+  return s;
+}
+
+static inline int FN(finbounds)(const FN(fvol_t)* V, REAL px, REAL py, REAL pz) {
+  return (px >= 0) & (py >= 0) & (pz >= 0) & (px < V->bx) & (py < V->by) & (pz < V->bz);
+}
+static inline int FN(fescaped)(const FN(fvol_t)* V, REAL px, REAL py, REAL pz, REAL vx, REAL vy, REAL vz) {
+  int ex = ((px < 0) & (vx < 0)) | ((px >= V->bx) & (vx > 0));
+  int ey = ((py < 0) & (vy < 0)) | ((py >= V->by) & (vy > 0));
+  int ez = ((pz < 0) & (vz < 0)) | ((pz >= V->bz) & (vz > 0));
+  return ex | ey | ez;
+}
+static inline REAL FN(fdot3)(REAL ax, REAL ay, REAL az, REAL bx, REAL by, REAL bz) {
+  return FMA(az, bz, FMA(ay, by, ax * bx));
+}
+
+typedef struct {
+  REAL x, y, z, vx, vy, vz, xtx, xty, xtz, vtx, vty, vtz, a0, a1, a2, a3, a4, a5;
+  int inside, esc, act; int steps;
+} FN(fstate_t);
+
+/* one forward iteration; mode 0 trace, 1 plane, 2 sdf, 3 target */
+static inline void FN(ffwd_step)(int mode, const FN(fvol_t)* V, const REAL* sdf, REAL ds, FN(fstate_t)* s) {
+  REAL n = 0, gx = 0, gy = 0, gz = 0;
+  if (s->inside) {
+    FN(fcell_t) c = FN(flocate)(V, s->x, s->y, s->z);
+    FN(fsample_t) q = FN(finterp)(V->data, &c);
+    n = q.n; gx = q.gx * V->inv_h; gy = q.gy * V->inv_h; gz = q.gz * V->inv_h;
+  }
+  REAL dsn = ds * n;
+  s->vx = FMA(dsn, gx, s->vx); s->vy = FMA(dsn, gy, s->vy); s->vz = FMA(dsn, gz, s->vz);
+  s->x = FMA(ds, s->vx, s->x); s->y = FMA(ds, s->vy, s->y); s->z = FMA(ds, s->vz, s->z);
+  int cur_inside;
+  if (mode == 2) {
+    REAL d = 0;
+    if (s->inside) { FN(fcell_t) c = FN(flocate)(V, s->x, s->y, s->z); d = FN(finterp)(sdf, &c).n; }
+    cur_inside = d < 0;
+  } else {
+    cur_inside = FN(finbounds)(V, s->x, s->y, s->z);
+    if (mode == 1) {
+      REAL d = FN(fdot3)(s->x - s->a0, s->y - s->a1, s->z - s->a2, s->a3, s->a4, s->a5);
+      cur_inside = cur_inside & !(d > 0);
+    }
+  }
+  int cross = s->inside & !cur_inside;
+  s->esc = s->esc | cross | FN(fescaped)(V, s->x, s->y, s->z, s->vx, s->vy, s->vz);
+  if (mode == 3) {
+    REAL ex = s->x - s->a0, ey = s->y - s->a1, ez = s->z - s->a2;
+    REAL cur = FN(fdot3)(ex, ey, ez, ex, ey, ez);
+    if (cur < s->a3) { s->xtx = s->x; s->xty = s->y; s->xtz = s->z; s->vtx = s->vx; s->vty = s->vy; s->vtz = s->vz; s->a3 = cur; }
+  } else if (cross) {
+    s->xtx = s->x; s->xty = s->y; s->xtz = s->z; s->vtx = s->vx; s->vty = s->vy; s->vtz = s->vz;
+  }
+  s->inside = cur_inside;
+}
+
+/* array-at-a-time forward march with the reference's global all(escaped) break
+ * (src/tracer.cpp:66-87, :135-159, :209-234, :280-302), factored arithmetic.           */
+static int FN(trace_fact)(int mode, const REAL* rif, const REAL* sdf, const int res[3], long long nvox,
+                          size_t N, const REAL* pos, const REAL* vel, const REAL* aux_a, const REAL* aux_b,
+                          REAL h, REAL ds, REAL* xt, REAL* vt, REAL* dist2, unsigned char* failmask,
+                          int* steps_out, long long* n_failed, int* iters_out) {
+  int rc = FN(check_res)(res, nvox); if (rc) return rc;
+  int max_steps = (mode == 2) ? (int)((REAL)2 * h * (REAL)FN(max3i)(res) / ds)
+                              : (int)((REAL)4 * h * (REAL)FN(max3i)(res) / ds);
+  FN(fvol_t) V; FN(fvol_make)(&V, rif, res, h);
+  FN(fstate_t)* S = (FN(fstate_t)*)malloc(sizeof(FN(fstate_t)) * (N ? N : 1));
+  for (size_t i = 0; i < N; ++i) {
+    FN(fstate_t)* s = S + i;
+    s->x = pos[3*i]; s->y = pos[3*i+1]; s->z = pos[3*i+2];
+    s->vx = vel[3*i]; s->vy = vel[3*i+1]; s->vz = vel[3*i+2];
+    s->xtx = s->x; s->xty = s->y; s->xtz = s->z; s->vtx = s->vx; s->vty = s->vy; s->vtz = s->vz;
+    s->a0 = s->a1 = s->a2 = s->a3 = s->a4 = s->a5 = 0;
+    if (mode == 1) { s->a0 = aux_a[3*i]; s->a1 = aux_a[3*i+1]; s->a2 = aux_a[3*i+2];
+                     s->a3 = aux_b[3*i]; s->a4 = aux_b[3*i+1]; s->a5 = aux_b[3*i+2]; }
+    if (mode == 3) { s->a0 = aux_a[3*i]; s->a1 = aux_a[3*i+1]; s->a2 = aux_a[3*i+2];
+                     REAL ex = s->x - s->a0, ey = s->y - s->a1, ez = s->z - s->a2;
+                     s->a3 = FN(fdot3)(ex, ey, ez, ex, ey, ez); }
+    s->inside = FN(finbounds)(&V, s->x, s->y, s->z);
+    s->esc = 0; s->act = 1; s->steps = 0;
+    if (mode == 2) { FN(fcell_t) c = FN(flocate)(&V, s->x, s->y, s->z); s->act = FN(finterp)(sdf, &c).n < 0; }
+  }
+  int it;
+  for (it = 0; it < max_steps; ++it) {
+    int all_escaped = 1;
+    for (size_t i = 0; i < N; ++i) {
+      FN(fstate_t)* s = S + i;
+      int was = s->esc;
+      FN(ffwd_step)(mode, &V, sdf, ds, s);          /* escaped rays keep updating (Q7) */
+      if (!was) s->steps = it + 1;
+      all_escaped &= s->esc;
+    }
+    if (all_escaped) { ++it; break; }
+  }
+  long long nf = 0;
+  for (size_t i = 0; i < N; ++i) {
+    FN(fstate_t)* s = S + i;
+    s->act = s->act & !s->esc;
+    nf += s->act;
+    if ((mode == 0 || mode == 1) && !s->esc) { s->xtx = s->x; s->xty = s->y; s->xtz = s->z; }
+    xt[3*i] = s->xtx; xt[3*i+1] = s->xty; xt[3*i+2] = s->xtz;
+    vt[3*i] = s->vtx; vt[3*i+1] = s->vty; vt[3*i+2] = s->vtz;
+    if (dist2) dist2[i] = s->a3;
+    if (failmask) failmask[i] = !s->esc;
+    if (steps_out) steps_out[i] = s->steps;
+  }
+  if (mode == 3) { nf = 0; for (size_t i = 0; i < N; ++i) nf += !S[i].esc; }
+  if (n_failed) *n_failed = nf;
+  if (iters_out) *iters_out = it;
+  free(S);
+  return 0;
+}
+
+typedef struct { REAL x, y, z, vx, vy, vz, lx, ly, lz, mx, my, mz; int active, outside; } FN(fadj_t);
+
+static int FN(backtrace_fact)(int use_sdf, const REAL* rif, const REAL* sdf, const int res[3], long long nvox,
+                              size_t N, const REAL* xt, const REAL* vt, const REAL* dx, const REAL* dv,
+                              REAL h, REAL ds, REAL grad_scale, REAL* grad, long long* steps_total) {
+  int rc = FN(check_res)(res, nvox); if (rc) return rc;
+  memset(grad, 0, sizeof(REAL) * (size_t)nvox);
+  int max_steps = (int)((REAL)2 * h * (REAL)FN(max3i)(res) / ds);
+  FN(fvol_t) V; FN(fvol_make)(&V, rif, res, h);
+  FN(fadj_t)* S = (FN(fadj_t)*)malloc(sizeof(FN(fadj_t)) * (N ? N : 1));
+  long long steps = 0;
+  for (size_t i = 0; i < N; ++i) {
+    FN(fadj_t)* s = S + i;
+    s->x = xt[3*i]; s->y = xt[3*i+1]; s->z = xt[3*i+2]; s->vx = vt[3*i]; s->vy = vt[3*i+1]; s->vz = vt[3*i+2];
+    s->lx = dx[3*i]; s->ly = dx[3*i+1]; s->lz = dx[3*i+2];
+    s->mx = FMA(ds, dx[3*i], dv[3*i]); s->my = FMA(ds, dx[3*i+1], dv[3*i+1]); s->mz = FMA(ds, dx[3*i+2], dv[3*i+2]);
+    s->active = !FN(fescaped)(&V, s->x, s->y, s->z, -s->vx, -s->vy, -s->vz);
+    s->outside = 0;
+    if (use_sdf && s->active) { FN(fcell_t) c = FN(flocate)(&V, s->x, s->y, s->z); s->outside = FN(finterp)(sdf, &c).n >= 0; }
+  }
+  for (int it = 0; it < max_steps; ++it) {
+    int any_active = 0;
+    for (size_t i = 0; i < N; ++i) {
+      FN(fadj_t)* s = S + i;
+      if (!s->active) continue;
+      s->x = FMA(-ds, s->vx, s->x); s->y = FMA(-ds, s->vy, s->y); s->z = FMA(-ds, s->vz, s->z);
+      FN(fcell_t) c = FN(flocate)(&V, s->x, s->y, s->z);
+      FN(fsample_t) q = FN(finterp)(rif, &c);
+      REAL n = q.n, gx = q.gx * V.inv_h, gy = q.gy * V.inv_h, gz = q.gz * V.inv_h;
+      REAL mdsn = -ds * n;
+      s->vx = FMA(mdsn, gx, s->vx); s->vy = FMA(mdsn, gy, s->vy); s->vz = FMA(mdsn, gz, s->vz);
+      int active = !FN(fescaped)(&V, s->x, s->y, s->z, -s->vx, -s->vy, -s->vz);
+      if (use_sdf) {
+        int now_out = FN(finterp)(sdf, &c).n >= 0;
+        active = active & !((!s->outside) & now_out);
+        s->outside = now_out;
+      }
+      s->active = active;
+      if (!active) continue;
+      any_active = 1; ++steps;
+      REAL dn = FN(fdot3)(s->mx, s->my, s->mz, gx, gy, gz);
+      REAL nds = (n * ds) * grad_scale;
+      REAL val = dn * ds, ggx = nds * s->mx, ggy = nds * s->my, ggz = nds * s->mz;
+      {   /* fused splat: 8 corner sums */
+        REAL x1 = c.wx, x0 = (REAL)1 - c.wx, y1 = c.wy, y0 = (REAL)1 - c.wy, z1 = c.wz, z0 = (REAL)1 - c.wz;
+        REAL a0 = FMA(val, x0, -ggx), a1 = FMA(val, x1, ggx);
+        REAL yz00 = y0*z0, yz10 = y1*z0, yz01 = y0*z1, yz11 = y1*z1;
+        REAL gyz0 = ggy*z0, gyz1 = ggy*z1, gzy0 = ggz*y0, gzy1 = ggz*y1;
+        REAL b00 = -gyz0 - gzy0, b10 = gyz0 - gzy1, b01 = gzy0 - gyz1, b11 = gyz1 + gzy1;
+        REAL* g = grad + c.base;
+        g[0]                   += FMA(yz00, a0, x0*b00);  g[c.ox]               += FMA(yz00, a1, x1*b00);
+        g[c.oy]                += FMA(yz10, a0, x0*b10);  g[c.oy + c.ox]        += FMA(yz10, a1, x1*b10);
+        g[c.oz]                += FMA(yz01, a0, x0*b01);  g[c.oz + c.ox]        += FMA(yz01, a1, x1*b01);
+        g[c.oz + c.oy]         += FMA(yz11, a0, x0*b11);  g[c.oz + c.oy + c.ox] += FMA(yz11, a1, x1*b11);
+      }
+      REAL hxy = q.hxy * V.inv_h2, hxz = q.hxz * V.inv_h2, hyz = q.hyz * V.inv_h2;
+      REAL hmx = FMA(hxz, s->mz, hxy * s->my);
+      REAL hmy = FMA(hyz, s->mz, hxy * s->mx);
+      REAL hmz = FMA(hyz, s->my, hxz * s->mx);
+      s->lx = FMA(ds, FMA(dn, gx, n*hmx), s->lx);
+      s->ly = FMA(ds, FMA(dn, gy, n*hmy), s->ly);
+      s->lz = FMA(ds, FMA(dn, gz, n*hmz), s->lz);
+      s->mx = FMA(ds, s->lx, s->mx); s->my = FMA(ds, s->ly, s->my); s->mz = FMA(ds, s->lz, s->mz);
+    }
+    if (!any_active) break;
+  }
+  if (steps_total) *steps_total = steps;
+  free(S);
+  return 0;
+}
+
+/* ---- cable, factored ---------------------------------------------------------------- */
+typedef struct { const REAL* data; int rres; REAL radius, length, h, inv_h, r2; } FN(fcyl_t);
+typedef struct { int i0, i1; REAL w0, r, rhx, rhz; int tiny; } FN(fcylcell_t);
+
+static inline FN(fcyl_t) FN(fcyl_make)(const REAL* data, int rres, REAL radius, REAL length) {
+  FN(fcyl_t) C; C.data = data; C.rres = rres; C.radius = radius; C.length = length;
+  C.h = radius / (REAL)(rres - 1); C.inv_h = (REAL)1 / C.h; C.r2 = radius * radius;
+  return C;
+}
+static inline FN(fcylcell_t) FN(fcyl_locate)(const FN(fcyl_t)* C, REAL px, REAL pz) {
+  FN(fcylcell_t) c;
+  REAL xs = px - C->radius, zs = pz - C->radius;
+  c.r = SQRT(FMA(xs, xs, zs*zs));
+  REAL rm = c.r * C->inv_h;
+  int ir = FN(f2i_sat)(FLOOR(rm));
+  c.i0 = FN(clampi)(ir, 0, C->rres - 1);
+  c.i1 = FN(clampi)(c.i0 + 1, 0, C->rres - 1);
+  c.w0 = rm - (REAL)c.i0;
+  c.tiny = c.r < (REAL)1e-6f;
+  REAL inv_r = c.tiny ? (REAL)0 : (REAL)1 / c.r;
+  c.rhx = xs * inv_r; c.rhz = zs * inv_r;
+  return c;
+}
+static inline int FN(fcyl_inbounds)(const FN(fcyl_t)* C, REAL px, REAL py, REAL pz) {
+  REAL xs = px - C->radius, zs = pz - C->radius;
+  return (FMA(xs, xs, zs*zs) < C->r2) & (py < C->length) & (py >= 0);
+}
+static inline int FN(fcyl_escaped)(const FN(fcyl_t)* C, REAL px, REAL py, REAL pz, REAL vx, REAL vy, REAL vz) {
+  REAL xs = px - C->radius, zs = pz - C->radius;
+  int esc_len = ((py < 0) & (vy < 0)) | ((py > C->length) & (vy > 0));
+  int out_r = FMA(xs, xs, zs*zs) >= C->r2;
+  int esc_r = FMA(xs, vx, zs*vz) > 0;
+  return (out_r & esc_r) | esc_len;
+}
+
+static int FN(trace_cable_fact)(const REAL* rif, size_t rres, REAL radius, REAL length, size_t N,
+                                const REAL* pos, const REAL* vel, const REAL* target, REAL ds,
+                                REAL* xt, REAL* vt, REAL* dist2, long long* n_failed, long long* steps_total) {
+  if (rres < 2) return -2;
+  int max_steps = (int)((REAL)4 * length / ds);
+  FN(fcyl_t) C = FN(fcyl_make)(rif, (int)rres, radius, length);
+  long long steps = 0, nf = 0;
+  for (size_t i = 0; i < N; ++i) {   /* ray-separable: masked state update freezes escaped rays */
+    REAL x = pos[3*i], y = pos[3*i+1], z = pos[3*i+2], vx = vel[3*i], vy = vel[3*i+1], vz = vel[3*i+2];
+    REAL xtx = x, xty = y, xtz = z, vtx = vx, vty = vy, vtz = vz;
+    REAL t0 = target[3*i], t1 = target[3*i+1], t2 = target[3*i+2];
+    REAL ex = x - t0, ey = y - t1, ez = z - t2;
+    REAL best = FN(fdot3)(ex, ey, ez, ex, ey, ez);
+    int inside = FN(fcyl_inbounds)(&C, x, y, z), esc = 0;
+    for (int it = 0; it < max_steps; ++it) {
+      FN(fcylcell_t) c = FN(fcyl_locate)(&C, x, z);
+      REAL v0 = rif[c.i0], v1 = rif[c.i1];
+      REAL f = FMA(v1, c.w0, v0 * ((REAL)1 - c.w0));
+      REAL rx = (v1 - v0) * C.inv_h;
+      REAL dsn = ds * f;
+      vx = FMA(dsn, rx * c.rhx, vx); vz = FMA(dsn, rx * c.rhz, vz);
+      x = FMA(ds, vx, x); y = FMA(ds, vy, y); z = FMA(ds, vz, z);
+      ex = x - t0; ey = y - t1; ez = z - t2;
+      REAL cur = FN(fdot3)(ex, ey, ez, ex, ey, ez);
+      int cur_inside = FN(fcyl_inbounds)(&C, x, y, z);
+      int cross = inside & !cur_inside;
+      esc = esc | cross | FN(fcyl_escaped)(&C, x, y, z, vx, vy, vz);
+      if (cur < best) { xtx = x; xty = y; xtz = z; vtx = vx; vty = vy; vtz = vz; best = cur; }
+      ++steps;
+      if (esc) break;
+      inside = cur_inside;
+    }
+    nf += !esc;
+    xt[3*i] = xtx; xt[3*i+1] = xty; xt[3*i+2] = xtz; vt[3*i] = vtx; vt[3*i+1] = vty; vt[3*i+2] = vtz;
+    dist2[i] = best;
+  }
+  if (n_failed) *n_failed = nf;
+  if (steps_total) *steps_total = steps;
+  return 0;
+}
+
+static int FN(backtrace_cable_fact)(const REAL* rif, size_t rres, REAL radius, REAL length, size_t N,
+                                    const REAL* xt, const REAL* vt, const REAL* dx, const REAL* dv,
+                                    REAL ds, REAL* grad, long long* steps_total) {
+  if (rres < 2) return -2;
+  memset(grad, 0, sizeof(REAL) * rres);
+  int max_steps = (int)((REAL)4 * length / ds);
+  FN(fcyl_t) C = FN(fcyl_make)(rif, (int)rres, radius, length);
+  long long steps = 0;
+  for (size_t i = 0; i < N; ++i) {
+    REAL x = xt[3*i], y = xt[3*i+1], z = xt[3*i+2], vx = vt[3*i], vy = vt[3*i+1], vz = vt[3*i+2];
+    REAL lx = dx[3*i], ly = dx[3*i+1], lz = dx[3*i+2];
+    REAL mx = FMA(ds, dx[3*i], dv[3*i]), my = FMA(ds, dx[3*i+1], dv[3*i+1]), mz = FMA(ds, dx[3*i+2], dv[3*i+2]);
+    int active = !FN(fcyl_escaped)(&C, x, y, z, -vx, -vy, -vz);
+    for (int it = 0; it < max_steps && active; ++it) {
+      x = FMA(-ds, vx, x); y = FMA(-ds, vy, y); z = FMA(-ds, vz, z);
+      FN(fcylcell_t) c = FN(fcyl_locate)(&C, x, z);
+      REAL v0 = rif[c.i0], v1 = rif[c.i1];
+      REAL w0 = c.w0, w1 = (REAL)1 - c.w0;
+      REAL n = FMA(v1, w0, v0 * w1);
+      REAL rx = (v1 - v0) * C.inv_h;
+      REAL gx = rx * c.rhx, gz = rx * c.rhz;
+      REAL mdsn = -ds * n;
+      vx = FMA(mdsn, gx, vx); vz = FMA(mdsn, gz, vz);
+      active = !FN(fcyl_escaped)(&C, x, y, z, -vx, -vy, -vz);
+      if (!active) break;
+      ++steps;
+      REAL dn = FMA(mz, gz, mx * gx);
+      REAL val = dn * ds;
+      REAL gv = (n * ds) * FMA(mz, c.rhz, mx * c.rhx);
+      REAL gvh = gv * C.inv_h;
+      grad[c.i0] += FMA(val, w1, -gvh);
+      grad[c.i1] += FMA(val, w0, gvh);
+      REAL sH = c.tiny ? (REAL)0 : rx / c.r;
+      REAL h00 = ((REAL)1 - c.rhx*c.rhx) * sH, h02 = -(c.rhx*c.rhz) * sH, h22 = ((REAL)1 - c.rhz*c.rhz) * sH;
+      REAL hmx = FMA(h02, mz, h00 * mx), hmz = FMA(h22, mz, h02 * mx);
+      lx = FMA(ds, FMA(dn, gx, n*hmx), lx);
+      lz = FMA(ds, FMA(dn, gz, n*hmz), lz);
+      mx = FMA(ds, lx, mx); my = FMA(ds, ly, my); mz = FMA(ds, lz, mz);
+    }
+  }
+  if (steps_total) *steps_total = steps;
+  return 0;
+}

@@ -39,6 +39,25 @@ def lib() -> C.CDLL:
     return _lib
 
 
+class arith:
+    """Context manager selecting the oracle's arithmetic mode: 'literal' (the reference's
+    expression order; default) or 'factored' (the explicit IEEE sequence of the HIP kernels)."""
+
+    def __init__(self, mode: str):
+        if mode not in ("literal", "factored"):
+            raise ValueError(mode)
+        self.mode = 1 if mode == "factored" else 0
+
+    def __enter__(self):
+        self.prev = lib().oracle_get_arith()
+        lib().oracle_set_arith(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_arith(self.prev)
+        return False
+
+
 def _sfx(dtype) -> str:
     dtype = np.dtype(dtype)
     if dtype == np.float32:

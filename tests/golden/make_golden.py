@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures (tests/golden/*.npz).
+
+Run ONCE in the build container, where /root/reference exists (it does not exist on the GPU
+box; nothing at test time reads it).  The reference's native path cannot run (enoki missing), so
+the fixtures are produced from the pieces of the reference that DO import here -- its pure-torch
+helpers -- plus the CPU oracle:
+
+  getlinear_grid.npz   core/grid.py  Grid.GetLinear   (:227-273) on the axis-permuted scene
+                       -> pins volume::eval_grad values, gradients, clamping, axis order (Q2)
+  getlinear_cable.npz  core/cable.py Cable.GetLinear  (:92-119)  -> pins cylinder_volume::eval_grad
+  luneburg_cube.npz    rays from core/source.py rand_rays_cube + random_rotate_ic (:398-412,:555-563),
+                       loss and (grad_x, grad_v) from core/sensor.py trace_rays_to_plane (:195-202)
+                       with the Luneburg loss of core/luneburg_opt.py:93-102; exit rays and dL/dn
+                       from the oracle (literal arithmetic, float64)
+  ad_vs_adjoint.npz    torch.autograd (float64) through oracle/torch_ad.py vs the oracle adjoint
+                       -> pins Tracer::backtrace as the exact discrete adjoint (h = 1 and h != 1, Q3)
+  fuel_injection.npz   data/fuel_injection_64.npy (float64, F-order) cast to fp32 and padded to 65^3
+                       as core/fuel_injection_opt.py:40-43 does; forward exit rays from the oracle
+
+Only DATA is stored (inputs and expected outputs); no reference source text.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/core")
+
+import cable as ref_cable      # noqa: E402
+import grid as ref_grid        # noqa: E402
+import sensor as ref_sensor    # noqa: E402
+import source as ref_source    # noqa: E402
+
+from oracle import oracle as O          # noqa: E402
+from oracle import torch_ad as TA       # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB", {k: np.asarray(v).shape for k, v in arrs.items()})
+
+
+def getlinear_grid():
+    torch.manual_seed(0)
+    R, h = 9, 0.25
+    scene = torch.rand(R, R, R, dtype=torch.float64) + 1.0           # our layout: scene[z,y,x]
+    G = ref_grid.Grid(scene.permute(2, 1, 0).contiguous(), h)        # reference layout: scene[x,y,z]
+    pts = torch.rand(400, 3, dtype=torch.float64) * (R + 1) * h - h  # includes out-of-range points
+    f, fx = G.GetLinear(pts)
+    save("getlinear_grid.npz", scene=scene.numpy(), h=h, pts=pts.numpy(), f=f.numpy(), fx=fx.numpy())
+
+
+def getlinear_cable():
+    torch.manual_seed(1)
+    rres, radius = 17, 2.0
+    prof = torch.rand(rres, dtype=torch.float64) + 1.0
+    Cb = ref_cable.Cable(prof, radius, 10.0)
+    pts = torch.rand(300, 3, dtype=torch.float64) * 2.4 * radius - 0.2 * radius
+    pts[0, 0] = radius; pts[0, 2] = radius                            # r = 0 -> zero gradient branch
+    f, fx = Cb.GetLinear(pts)
+    save("getlinear_cable.npz", prof=prof.numpy(), radius=radius, pts=pts.numpy(), f=f.numpy(), fx=fx.numpy())
+
+
+def luneburg_cube():
+    torch.manual_seed(0)
+    np.random.seed(0)                                                 # scipy Rotation.random()
+    R, span, nb = 17, 20.0, 12
+    h = span / (R - 1)
+    ds = h / 2
+    g = np.linspace(0, span, R)
+    Z, Y, X = np.meshgrid(g, g, g, indexing="ij")
+    r = np.sqrt((X - span / 2) ** 2 + (Y - span / 2) ** 2 + (Z - span / 2) ** 2) / (span / 2)
+    rif = np.sqrt(2 - np.minimum(r, 1.0) ** 2).astype(np.float32)
+    (x, v, planes), rpv = ref_source.rand_rays_cube((nb, nb), 1, span, circle=True, src_type="plane")
+    x, v, planes = ref_source.random_rotate_ic(x, v, planes, span)
+    x, v, planes = x.float(), v.float(), planes.float()
+    o = O.trace(rif, rif.shape, x.numpy(), v.numpy(), h, ds, dtype=np.float64)
+    xm = torch.tensor(o["xt"], requires_grad=True)
+    vm = torch.tensor(o["vt"], requires_grad=True)
+    sn = planes[:, 1, :].double()
+    sp = planes[:, 0, :].double()
+    xmp, _ = ref_sensor.trace_rays_to_plane((xm, vm), (sp, sn))
+    loss = torch.sum((xmp - sp) ** 2) / x.shape[0] / span             # core/luneburg_opt.py:100-102
+    loss.backward()
+    b = O.backtrace(rif, rif.shape, o["xt"], o["vt"], xm.grad.numpy(), vm.grad.numpy(), h, ds, dtype=np.float64)
+    bc = O.backtrace(rif, rif.shape, o["xt"], o["vt"], xm.grad.numpy(), vm.grad.numpy(), h, ds, dtype=np.float64,
+                     corrected_h=True)
+    save("luneburg_cube.npz", rif=rif, h=h, ds=ds, x=x.numpy(), v=v.numpy(), planes=planes.numpy(),
+         rpv=np.asarray(rpv), xt=o["xt"], vt=o["vt"], steps=o["steps"], loss=float(loss),
+         grad_x=xm.grad.numpy(), grad_v=vm.grad.numpy(), drif=b["grad"], drif_corrected=bc["grad"])
+
+
+def ad_vs_adjoint():
+    torch.manual_seed(1)
+    R, N = 9, 96
+    rif = (1 + 0.3 * torch.rand(R, R, R, dtype=torch.float64))
+    pos0 = torch.rand(N, 3, dtype=torch.float64) * (R - 1)
+    vel = torch.tensor([[0.1, 1.0, 0.05]], dtype=torch.float64).repeat(N, 1)
+    vel = vel / vel.norm(dim=-1, keepdim=True)
+    out = dict(rif=rif.numpy(), vel=vel.numpy())
+    for tag, h in (("h1", 1.0), ("h05", 0.5)):
+        ds = h / 2
+        p = pos0 * h
+        p[:, 1] = -0.3 * ds                                           # off-face start (no termination ties)
+        rr = rif.clone().requires_grad_(True)
+        xt, vt = TA.trace(rr, p, vel, h, ds)
+        gx, gv = torch.randn_like(xt), torch.randn_like(vt)
+        ((xt * gx).sum() + (vt * gv).sum()).backward()
+        out.update({f"{tag}_h": h, f"{tag}_ds": ds, f"{tag}_pos": p.numpy(), f"{tag}_xt": xt.detach().numpy(),
+                    f"{tag}_vt": vt.detach().numpy(), f"{tag}_gx": gx.numpy(), f"{tag}_gv": gv.numpy(),
+                    f"{tag}_ad_grad": rr.grad.numpy()})
+    save("ad_vs_adjoint.npz", **out)
+
+
+def fuel_injection():
+    torch.manual_seed(0)
+    data = np.load("/root/reference/data/fuel_injection_64.npy")      # (64,64,64) float64, F-order
+    fuel_val = 0.0003
+    vol = np.full((65, 65, 65), 1 + fuel_val, dtype=np.float32)       # core/fuel_injection_opt.py:40-42
+    vol[:-1, :-1, :-1] = np.ascontiguousarray(data).astype(np.float32)
+    span = 1.0
+    h = span / 64
+    ds = h / 2
+    (x, v, planes), nrays = ref_source.rand_rays_in_sphere(3, (24, 24), 1, span, angle_span=180, circle=False,
+                                                           xaxis=False, sensor_dist=1.0)
+    x, v = x.float().numpy(), v.float().numpy()
+    o = O.trace(vol, vol.shape, x, v, h, ds, dtype=np.float64)
+    save("fuel_injection.npz", vol=vol, h=h, ds=ds, x=x, v=v, xt=o["xt"], vt=o["vt"], steps=o["steps"])
+
+
+if __name__ == "__main__":
+    getlinear_grid()
+    getlinear_cable()
+    luneburg_cube()
+    ad_vs_adjoint()
+    fuel_injection()

@@ -1,0 +1,122 @@
+// hostcheck.hip -- TEST INFRASTRUCTURE ONLY (never built or loaded by the package).
+//
+// Compiles the product's own per-ray code (adjointnonlinearraytracing_amd/csrc/drrt_device.h,
+// the __host__ __device__ step functions and whole-ray drivers the kernels call) for the HOST
+// with `hipcc --cuda-host-only -ffp-contract=off`, so that the CPU-only test tier can compare the
+// product's arithmetic and control flow with the oracle's `factored` mode bit for bit, without a
+// GPU.  The real kernels are exercised by the `-m gpu` tests.
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#include "../../adjointnonlinearraytracing_amd/csrc/drrt_device.h"
+
+using namespace drrt;
+
+static Vol make_vol(const float* data, const int res[3], float h) {
+  Vol V;
+  V.data = data; V.W = res[0]; V.H = res[1]; V.D = res[2]; V.sy = res[0]; V.sz = res[0] * res[1];
+  V.inv_h = 1.0f / h; V.inv_h2 = V.inv_h * V.inv_h;
+  V.bx = (float)(res[0] - 1) * h; V.by = (float)(res[1] - 1) * h; V.bz = (float)(res[2] - 1) * h;
+  return V;
+}
+static int max3(const int r[3]) { return r[0] > r[1] ? (r[0] > r[2] ? r[0] : r[2]) : (r[1] > r[2] ? r[1] : r[2]); }
+
+#define EXPORT extern "C" __attribute__((visibility("default")))
+
+// mode 0 trace, 1 plane, 2 sdf
+EXPORT int hostcheck_trace(int mode, const float* rif, const float* sdf, const int* res, size_t n,
+                           const float* pos, const float* vel, const float* pln_o, const float* pln_d,
+                           float h, float ds, float* xt, float* vt, uint8_t* failmask, int* steps,
+                           long long* n_failed) {
+  Vol V = make_vol(rif, res, h);
+  int max_steps = (mode == 2) ? (int)(2.0f * h * (float)max3(res) / ds) : (int)(4.0f * h * (float)max3(res) / ds);
+  long long nf = 0;
+  const float zero[3] = {0, 0, 0};
+  for (size_t i = 0; i < n; ++i) {
+    const float* po = pln_o ? pln_o + 3 * i : zero; const float* pd = pln_d ? pln_d + 3 * i : zero;
+    RayOut r = mode == 0 ? trace_ray<0>(V, sdf, ds, max_steps, pos + 3 * i, vel + 3 * i, po, pd)
+             : mode == 1 ? trace_ray<1>(V, sdf, ds, max_steps, pos + 3 * i, vel + 3 * i, po, pd)
+                         : trace_ray<2>(V, sdf, ds, max_steps, pos + 3 * i, vel + 3 * i, po, pd);
+    memcpy(xt + 3 * i, r.xt, 12); memcpy(vt + 3 * i, r.vt, 12);
+    if (failmask) failmask[i] = r.esc ? 0 : 1;
+    if (steps) steps[i] = (int)r.steps;
+    nf += r.act ? 1 : 0;
+  }
+  if (n_failed) *n_failed = nf;
+  return 0;
+}
+
+EXPORT int hostcheck_trace_target(const float* rif, const int* res, size_t n, const float* pos, const float* vel,
+                                  const float* target, float h, float ds, float* xt, float* vt, float* dist2,
+                                  int* iters) {
+  Vol V = make_vol(rif, res, h);
+  int max_steps = (int)(4.0f * h * (float)max3(res) / ds);
+  float* cont = new float[6 * (n ? n : 1)];
+  unsigned* done = new unsigned[n ? n : 1];
+  unsigned total = 0;
+  for (size_t i = 0; i < n; ++i) {                       // phase A (k_target_a)
+    RayOut r = target_ray_a(V, ds, max_steps, pos + 3 * i, vel + 3 * i, target + 3 * i, cont + 6 * i);
+    memcpy(xt + 3 * i, r.xt, 12); memcpy(vt + 3 * i, r.vt, 12); dist2[i] = r.dist2;
+    done[i] = r.steps; if (r.steps > total) total = r.steps;
+  }
+  for (size_t i = 0; i < n; ++i) {                       // phase B (k_target_b)
+    if (done[i] >= total) continue;
+    float best = dist2[i], x3[3], v3[3];
+    if (target_ray_b(ds, done[i], total, cont + 6 * i, target + 3 * i, best, x3, v3)) {
+      memcpy(xt + 3 * i, x3, 12); memcpy(vt + 3 * i, v3, 12); dist2[i] = best;
+    }
+  }
+  if (iters) *iters = (int)total;
+  delete[] cont; delete[] done;
+  return 0;
+}
+
+EXPORT int hostcheck_backtrace(int use_sdf, const float* rif, const float* sdf, const int* res, size_t n,
+                               const float* xt, const float* vt, const float* dx, const float* dv,
+                               float h, float ds, float grad_scale, float* grad, long long* steps_total) {
+  Vol V = make_vol(rif, res, h);
+  int max_steps = (int)(2.0f * h * (float)max3(res) / ds);
+  memset(grad, 0, sizeof(float) * (size_t)res[0] * res[1] * res[2]);
+  long long st = 0;
+  auto sink = [grad](const Cell& c, const Corners& w) {
+    float* g = grad + c.base;
+    g[0] += w.c000;            g[c.ox] += w.c100;
+    g[c.oy] += w.c010;         g[c.oy + c.ox] += w.c110;
+    g[c.oz] += w.c001;         g[c.oz + c.ox] += w.c101;
+    g[c.oz + c.oy] += w.c011;  g[c.oz + c.oy + c.ox] += w.c111;
+  };
+  for (size_t i = 0; i < n; ++i)
+    st += use_sdf ? backtrace_ray<1>(V, sdf, ds, grad_scale, max_steps, xt + 3 * i, vt + 3 * i, dx + 3 * i, dv + 3 * i, sink)
+                  : backtrace_ray<0>(V, sdf, ds, grad_scale, max_steps, xt + 3 * i, vt + 3 * i, dx + 3 * i, dv + 3 * i, sink);
+  if (steps_total) *steps_total = st;
+  return 0;
+}
+
+EXPORT int hostcheck_trace_cable(const float* rif, int rres, float radius, float length, size_t n,
+                                 const float* pos, const float* vel, const float* target, float ds,
+                                 float* xt, float* vt, float* dist2, long long* steps_total) {
+  Cyl C = make_cyl(rif, rres, radius, length);
+  int max_steps = (int)(4.0f * length / ds);
+  long long st = 0;
+  for (size_t i = 0; i < n; ++i) {
+    RayOut r = cable_trace_ray(C, ds, max_steps, pos + 3 * i, vel + 3 * i, target + 3 * i);
+    memcpy(xt + 3 * i, r.xt, 12); memcpy(vt + 3 * i, r.vt, 12); dist2[i] = r.dist2; st += r.steps;
+  }
+  if (steps_total) *steps_total = st;
+  return 0;
+}
+
+EXPORT int hostcheck_backtrace_cable(const float* rif, int rres, float radius, float length, size_t n,
+                                     const float* xt, const float* vt, const float* dx, const float* dv,
+                                     float ds, float* grad, long long* steps_total) {
+  Cyl C = make_cyl(rif, rres, radius, length);
+  int max_steps = (int)(4.0f * length / ds);
+  memset(grad, 0, sizeof(float) * rres);
+  long long st = 0;
+  auto sink = [grad](int i0, int i1, float a0, float a1) { grad[i0] += a0; grad[i1] += a1; };
+  for (size_t i = 0; i < n; ++i)
+    st += cable_backtrace_ray(C, ds, max_steps, xt + 3 * i, vt + 3 * i, dx + 3 * i, dv + 3 * i, sink);
+  if (steps_total) *steps_total = st;
+  return 0;
+}

@@ -1,0 +1,101 @@
+"""CPU tier: the product's own per-ray code (csrc/drrt_device.h: the __host__ __device__ step
+functions and whole-ray drivers the HIP kernels call), compiled for the host by tests/hostcheck,
+must agree BIT FOR BIT with the oracle's `factored` float32 arithmetic on trajectories, exit steps
+and closest-approach records; adjoint grids agree up to summation order.  This also validates the
+per-ray termination / two-phase trace_target restructuring against the reference's global-loop
+semantics, which the oracle keeps."""
+import numpy as np
+import pytest
+
+import cases
+import hostcheck_lib as H
+
+
+@pytest.fixture(scope="module")
+def scene():
+    R, span = 33, 1.0
+    h = span / (R - 1); ds = h / 2
+    pos, vel = cases.cube_rays(400, span, ds, seed=1, tilt=0.15)
+    rng = np.random.default_rng(3)
+    return dict(R=R, span=span, h=h, ds=ds, pos=pos, vel=vel,
+                dx=rng.normal(size=pos.shape).astype(np.float32), dv=rng.normal(size=pos.shape).astype(np.float32))
+
+
+@pytest.mark.parametrize("kind", ["luneburg", "smooth", "uniform"])
+def test_trace_and_backtrace_bitwise(oracle, scene, kind):
+    R, h, ds, pos, vel = scene["R"], scene["h"], scene["ds"], scene["pos"], scene["vel"]
+    rif = {"luneburg": cases.luneburg(R), "smooth": cases.smooth_field(R, 3),
+           "uniform": np.full((R, R, R), 1.2, np.float32)}[kind]
+    with oracle.arith("factored"):
+        o = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float32)
+    k = H.trace(rif, rif.shape, pos, vel, h, ds)
+    assert np.array_equal(o["xt"], k["xt"]) and np.array_equal(o["vt"], k["vt"])
+    assert np.array_equal(o["steps"], k["steps"]) and o["n_failed"] == k["n_failed"]
+    for corr in (False, True):
+        with oracle.arith("factored"):
+            ob = oracle.backtrace(rif, rif.shape, k["xt"], k["vt"], scene["dx"], scene["dv"], h, ds,
+                                  dtype=np.float32, corrected_h=corr)
+        kb = H.backtrace(rif, rif.shape, k["xt"], k["vt"], scene["dx"], scene["dv"], h, ds, corrected_h=corr)
+        assert ob["steps_total"] == kb["steps_total"]
+        assert cases.rel_l2(kb["grad"], ob["grad"]) < 2e-6          # same terms, different summation order
+
+
+def test_plane_target_sdf_bitwise(oracle, scene):
+    R, span, h, ds, pos, vel = scene["R"], scene["span"], scene["h"], scene["ds"], scene["pos"], scene["vel"]
+    rif = cases.luneburg(R)
+    po = np.tile(np.array([[0.5, 0.7, 0.5]], np.float32), (len(pos), 1))
+    pd = np.tile(np.array([[0, 1, 0]], np.float32), (len(pos), 1))
+    with oracle.arith("factored"):
+        op = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float32, mode="plane", pln_o=po, pln_d=pd)
+    kp = H.trace(rif, rif.shape, pos, vel, h, ds, mode="plane", pln_o=po, pln_d=pd)
+    assert np.array_equal(op["xt"], kp["xt"]) and np.array_equal(op["vt"], kp["vt"])
+    assert np.array_equal(op["failmask"], kp["failmask"])
+    # target beyond the far face AND a target inside the volume: both sides of the global-loop coupling
+    for tgt in ([0.5, 1.3, 0.5], [0.5, 0.6, 0.5], [-0.4, 0.2, 0.5]):
+        tg = np.tile(np.array([tgt], np.float32), (len(pos), 1))
+        with oracle.arith("factored"):
+            ot = oracle.trace_target(rif, rif.shape, pos, vel, tg, h, ds, dtype=np.float32)
+        kt = H.trace_target(rif, rif.shape, pos, vel, tg, h, ds)
+        assert ot["iters"] == kt["iters"]
+        assert np.array_equal(ot["xt"], kt["xt"]) and np.array_equal(ot["vt"], kt["vt"])
+        assert np.array_equal(ot["dist2"], kt["dist2"])
+    sdf = cases.sphere_sdf(R, span, 0.4)
+    rng = np.random.default_rng(2)
+    d = rng.normal(size=(len(pos), 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ins = (0.5 * span + 0.2 * span * rng.uniform(0, 1, (len(pos), 1)) ** (1 / 3) * d).astype(np.float32)
+    with oracle.arith("factored"):
+        os_ = oracle.trace(rif, rif.shape, ins, vel, h, ds, dtype=np.float32, mode="sdf", sdf=sdf)
+    ks = H.trace(rif, rif.shape, ins, vel, h, ds, mode="sdf", sdf=sdf)
+    assert np.array_equal(os_["xt"], ks["xt"]) and np.array_equal(os_["vt"], ks["vt"])
+    assert os_["n_failed"] == ks["n_failed"]
+    with oracle.arith("factored"):
+        ob = oracle.backtrace(rif, rif.shape, ks["xt"], ks["vt"], scene["dx"], scene["dv"], h, ds,
+                              dtype=np.float32, sdf=sdf)
+    kb = H.backtrace(rif, rif.shape, ks["xt"], ks["vt"], scene["dx"], scene["dv"], h, ds, sdf=sdf)
+    assert ob["steps_total"] == kb["steps_total"] and cases.rel_l2(kb["grad"], ob["grad"]) < 2e-6
+
+
+def test_cable_bitwise(oracle):
+    rres, radius, length = 65, 1.0, 6.0
+    ds = radius / rres / 2
+    prof = np.sqrt(2.0 - np.linspace(0, 1, rres) ** 2).astype(np.float32)
+    rng = np.random.default_rng(4)
+    n = 500
+    ang = rng.uniform(0, 2 * np.pi, n); rad = 0.8 * radius * np.sqrt(rng.uniform(0, 1, n))
+    pos = np.stack([radius + rad * np.cos(ang), np.full(n, 0.37 * ds), radius + rad * np.sin(ang)], -1).astype(np.float32)
+    pos[0] = [radius, 0.37 * ds, radius]                                   # on the axis: r < eps branch
+    vel = rng.normal(0, 0.05, (n, 3)); vel[:, 1] = 1.0
+    vel = (vel / np.linalg.norm(vel, axis=1, keepdims=True)).astype(np.float32)
+    vel[0] = [0, 1, 0]
+    tg = np.stack([np.full(n, radius), np.full(n, 0.75 * length), np.full(n, radius)], -1).astype(np.float32)
+    with oracle.arith("factored"):
+        o = oracle.trace_cable(prof, radius, length, pos, vel, tg, ds, dtype=np.float32)
+    k = H.trace_cable(prof, radius, length, pos, vel, tg, ds)
+    assert np.array_equal(o["xt"], k["xt"]) and np.array_equal(o["vt"], k["vt"]) and np.array_equal(o["dist2"], k["dist2"])
+    assert o["steps_total"] == k["steps_total"]
+    dx = rng.normal(size=pos.shape).astype(np.float32); dv = rng.normal(size=pos.shape).astype(np.float32)
+    with oracle.arith("factored"):
+        ob = oracle.backtrace_cable(prof, radius, length, k["xt"], k["vt"], dx, dv, ds, dtype=np.float32)
+    kb = H.backtrace_cable(prof, radius, length, k["xt"], k["vt"], dx, dv, ds)
+    assert ob["steps_total"] == kb["steps_total"]
+    assert np.array_equal(ob["grad"], kb["grad"])       # same ray-major summation order: bitwise

@@ -1,0 +1,264 @@
+"""CPU tier: pins the oracle (oracle/) -- golden fixtures generated from the reference's importable
+torch helpers (tests/golden/make_golden.py), closed-form known-answer tests
+and the literal-vs-factored arithmetic cross-check."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+# ------------------------------------------------------------------------------------ golden
+def test_eval_grad_matches_reference_getlinear(oracle):
+    """volume::eval_grad == core/grid.py Grid.GetLinear on the axis-permuted scene (Q2), incl.
+    out-of-range points (clamping, Q11).  float64: agreement at rounding level."""
+    z = load("getlinear_grid.npz")
+    R = z["scene"].shape[0]
+    n, g = oracle.eval_grad(z["scene"], (R, R, R), float(z["h"]), z["pts"], dtype=np.float64)
+    assert np.abs(n - z["f"]).max() < 1e-13
+    assert np.abs(g - z["fx"]).max() < 1e-12
+    n32, g32 = oracle.eval_grad(z["scene"], (R, R, R), float(z["h"]), z["pts"], dtype=np.float32)
+    assert np.abs(n32 - z["f"]).max() < 1e-6 and np.abs(g32 - z["fx"]).max() < 2e-5
+
+
+def test_cyl_eval_grad_matches_reference_cable(oracle):
+    """cylinder_volume::eval_grad == core/cable.py Cable.GetLinear (:92-119) inside the profile.
+    Beyond the last sample the two differ by design (Cable clips w0 to [0,1] and indexes x0+1
+    before clamping; cylinder_volume clamps idx0 first, src/cylinder_volume.cpp:45-48) -- both
+    give the boundary value and zero gradient there."""
+    z = load("getlinear_cable.npz")
+    radius = float(z["radius"])
+    n, g = oracle.cyl_eval_grad(z["prof"], radius, z["pts"], dtype=np.float64)
+    r = np.hypot(z["pts"][:, 0] - radius, z["pts"][:, 2] - radius)
+    inside = r < radius * (1 - 1e-9)
+    assert inside.sum() > 50
+    assert np.abs(n[inside] - z["f"][inside]).max() < 1e-13
+    assert np.abs(g[inside] - z["fx"][inside]).max() < 1e-11
+    assert np.abs(n[~inside] - z["prof"][-1]).max() < 1e-13 and np.abs(g[~inside]).max() == 0.0
+    assert np.all(g[0] == 0.0)                      # r = 0 branch (:56)
+
+
+@pytest.mark.parametrize("tag", ["h1", "h05"])
+def test_adjoint_is_exact_discrete_adjoint(oracle, tag):
+    """torch.autograd (float64) through the torch restatement of trace vs Tracer::backtrace.
+    h = 1: as-written adjoint is exact.  h = 0.5: as written it is off by the missing 1/h on the
+    gradient splat (Q3, rel-L2 ~ 0.5); DRRT_FLAG_CORRECTED_H restores exactness."""
+    z = load("ad_vs_adjoint.npz")
+    rif, vel = z["rif"], z["vel"]
+    h, ds = float(z[f"{tag}_h"]), float(z[f"{tag}_ds"])
+    o = oracle.trace(rif, rif.shape, z[f"{tag}_pos"], vel, h, ds, dtype=np.float64)
+    assert np.abs(o["xt"] - z[f"{tag}_xt"]).max() < 1e-12 and np.abs(o["vt"] - z[f"{tag}_vt"]).max() < 1e-12
+    ad = z[f"{tag}_ad_grad"]
+    for mode in ("literal", "factored"):
+        with oracle.arith(mode):
+            exact = oracle.backtrace(rif, rif.shape, o["xt"], o["vt"], z[f"{tag}_gx"], z[f"{tag}_gv"], h, ds,
+                                     dtype=np.float64, corrected_h=True)["grad"]
+            written = oracle.backtrace(rif, rif.shape, o["xt"], o["vt"], z[f"{tag}_gx"], z[f"{tag}_gv"], h, ds,
+                                       dtype=np.float64, corrected_h=False)["grad"]
+        assert cases.rel_l2(exact, ad) < 1e-12
+        if tag == "h1":
+            assert cases.rel_l2(written, ad) < 1e-12
+        else:
+            assert 0.3 < cases.rel_l2(written, ad) < 0.7
+
+
+def _plane_loss_np(xt, vt, planes, span):
+    """core/sensor.py:195-202 trace_rays_to_plane + core/luneburg_opt.py:100-102 loss, in numpy."""
+    sp, sn = planes[:, 0, :].astype(np.float64), planes[:, 1, :].astype(np.float64)
+    t = np.einsum("ij,ij->i", sn, sp - xt) / np.einsum("ij,ij->i", sn, vt)
+    xp = xt + t[:, None] * vt
+    return float(np.sum((xp - sp) ** 2) / len(xt) / span)
+
+
+def test_luneburg_cube_fixture(oracle):
+    """Rays from core/source.py rand_rays_cube + random_rotate_ic; loss / (grad_x, grad_v) from
+    core/sensor.py.  The oracle must reproduce the stored exit rays and dL/dn (regression pin),
+    and its float32 instantiations must agree within fp32 tolerance."""
+    z = load("luneburg_cube.npz")
+    rif, h, ds = z["rif"], float(z["h"]), float(z["ds"])
+    span = h * (rif.shape[0] - 1)
+    o = oracle.trace(rif, rif.shape, z["x"], z["v"], h, ds, dtype=np.float64)
+    assert np.abs(o["xt"] - z["xt"]).max() < 1e-11 and np.array_equal(o["steps"], z["steps"])
+    assert abs(_plane_loss_np(o["xt"], o["vt"], z["planes"], span) - float(z["loss"])) < 1e-10
+    b = oracle.backtrace(rif, rif.shape, o["xt"], o["vt"], z["grad_x"], z["grad_v"], h, ds, dtype=np.float64)
+    assert cases.rel_l2(b["grad"], z["drif"]) < 1e-11
+    bc = oracle.backtrace(rif, rif.shape, o["xt"], o["vt"], z["grad_x"], z["grad_v"], h, ds, dtype=np.float64,
+                          corrected_h=True)
+    assert cases.rel_l2(bc["grad"], z["drif_corrected"]) < 1e-11
+    for mode in ("literal", "factored"):
+        with oracle.arith(mode):
+            o32 = oracle.trace(rif, rif.shape, z["x"], z["v"], h, ds, dtype=np.float32)
+        d = np.linalg.norm(o32["xt"] - z["xt"], axis=1)
+        assert np.mean(d <= 2e-5 * span) >= 0.99          # cell-face ties may displace a few rays
+
+
+def test_fuel_injection_fixture(oracle):
+    """Real data (data/fuel_injection_64.npy padded to 65^3): weak deflection, n in [1, 1.0003]."""
+    z = load("fuel_injection.npz")
+    vol, h, ds = z["vol"], float(z["h"]), float(z["ds"])
+    assert vol.shape == (65, 65, 65) and 1.0 <= vol.min() and vol.max() <= 1.0003 + 1e-6
+    o = oracle.trace(vol, vol.shape, z["x"], z["v"], h, ds, dtype=np.float64)
+    assert np.abs(o["xt"] - z["xt"]).max() < 1e-11 and np.array_equal(o["steps"], z["steps"])
+    with oracle.arith("factored"):
+        o32 = oracle.trace(vol, vol.shape, z["x"], z["v"], h, ds, dtype=np.float32)
+    # the 0-degree view marches along +y in exact multiples of ds, so samples land ON the far face
+    # (y = 64 h) up to rounding: fp32 and fp64 may exit one step apart there (Q16) -- nothing else
+    bad, unexplained = cases.step_flip_report(o32["xt"], o32["vt"], z["xt"], z["vt"], ds, tol=2e-5)
+    assert unexplained <= 0.002 and bad <= 0.05
+    # nearly straight rays: the exit direction deviates from the entry direction by < 1e-2 rad
+    assert np.abs(o["vt"] - z["v"]).max() < 1e-2
+
+
+# ------------------------------------------------------------------------------------ KATs
+def test_uniform_medium_closed_form(oracle):
+    """rif = c: straight rays; exit step K = min{k : z0 + k ds >= (R-1) h} (strict <, Q8);
+    adjoint: value splat 0 and the 8 gradient-splat weights sum to 0 => sum(dL/dn) = 0."""
+    R, h, ds = 33, 1.0, 0.5
+    rif = np.full((R, R, R), 1.3, np.float32)
+    g = np.linspace(0.5, 31.5, 8, dtype=np.float32)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    pos = np.stack([X.ravel(), Y.ravel(), np.full(X.size, 0.25, np.float32)], -1)
+    vel = np.tile(np.array([[0, 0, 1]], np.float32), (len(pos), 1))
+    for dtype in (np.float32, np.float64):
+        for mode in ("literal", "factored"):
+            with oracle.arith(mode):
+                o = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=dtype)
+                K = int(np.ceil((32 - 0.25) / ds))
+                assert np.all(o["steps"] == K) and o["iters"] == K and o["n_failed"] == 0
+                assert np.all(o["xt"][:, 2] == 0.25 + K * ds) and np.array_equal(o["vt"], vel.astype(dtype))
+                b = oracle.backtrace(rif, rif.shape, o["xt"], o["vt"], np.ones_like(pos), np.ones_like(pos), h, ds,
+                                     dtype=dtype)
+                assert abs(b["grad"].sum()) <= 1e-4 * np.abs(b["grad"]).sum()
+                assert b["steps_total"] == len(pos) * K      # reverse march: K samples back to z = 0.25
+
+
+def test_linear_field_matches_analytic_recurrence(oracle):
+    """n = a + b.p is reproduced exactly by trilinear interpolation (Hessian 0): the march must
+    equal a float64 recurrence with the analytic n and grad n."""
+    R, span = 17, 1.0
+    h = span / (R - 1); ds = h / 2
+    a, b = 1.0, np.array([0.10, 0.25, -0.05])
+    g = np.linspace(0, span, R)
+    Z, Y, X = np.meshgrid(g, g, g, indexing="ij")
+    rif = a + b[0] * X + b[1] * Y + b[2] * Z
+    pos, vel = cases.plane_rays(200, span, ds, seed=2, tilt=0.1, lo=0.3, hi=0.7)
+    pos, vel = pos.astype(np.float64), vel.astype(np.float64)
+    o = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float64)
+    x, v = pos.copy(), vel.copy()
+    xt = pos.copy(); done = np.zeros(len(pos), bool); was_in = np.zeros(len(pos), bool)
+    for _ in range(int(o["iters"])):
+        inside = np.all((x >= 0) & (x < span), axis=1)
+        n = np.where(inside, a + x @ b, 0.0)
+        v = v + ds * n[:, None] * np.where(inside[:, None], b[None, :], 0.0)
+        x = x + ds * v
+        now_in = np.all((x >= 0) & (x < span), axis=1)
+        cross = inside & ~now_in & ~done
+        xt[cross] = x[cross]; done |= cross
+    assert done.all()
+    assert np.abs(o["xt"] - xt).max() < 1e-11
+    Hm = oracle.eval_hess(rif, rif.shape, h, pos[:50] * 0 + 0.4, dtype=np.float64)
+    assert np.abs(Hm).max() < 1e-9
+
+
+def test_luneburg_lens_focuses_parallel_rays(oracle):
+    """Luneburg profile n(r) = sqrt(2 - r^2): parallel rays focus at the antipodal surface point
+    (the reference's ground truth, core/fiber_opt.py:165-166) up to discretisation."""
+    R, span = 65, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = cases.luneburg(R, span)
+    rng = np.random.default_rng(0)
+    ang = rng.uniform(0, 2 * np.pi, 300); rad = 0.35 * span * np.sqrt(rng.uniform(0, 1, 300))
+    pos = np.stack([0.5 * span + rad * np.cos(ang), np.full(300, -0.3 * ds), 0.5 * span + rad * np.sin(ang)], -1)
+    vel = np.tile([[0.0, 1.0, 0.0]], (300, 1))
+    o = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float64)
+    t = (span - o["xt"][:, 1]) / o["vt"][:, 1]
+    hit = o["xt"] + t[:, None] * o["vt"]
+    miss = np.linalg.norm(hit[:, [0, 2]] - 0.5 * span, axis=1)
+    assert np.median(miss) < 1.0 * h and miss.max() < 3.0 * h
+
+
+# ------------------------------------------------------------------------------------ arithmetic modes
+def test_factored_arithmetic_equals_literal_in_float64(oracle):
+    """The factored op sequence (what the GPU runs) is the same algorithm as the literal one:
+    float64 trajectories agree to ~1e-12 and gradients to ~1e-11 for every variant."""
+    R, span = 17, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = cases.smooth_field(R, seed=3).astype(np.float64)
+    sdf = cases.sphere_sdf(R, span, 0.4).astype(np.float64)
+    pos, vel = cases.cube_rays(150, span, ds, seed=1)
+    rng = np.random.default_rng(1)
+    dx, dv = rng.normal(size=pos.shape), rng.normal(size=pos.shape)
+    po = np.tile([[0.5, 0.7, 0.5]], (len(pos), 1)); pd = np.tile([[0.0, 1.0, 0.0]], (len(pos), 1))
+    tg = np.tile([[0.5, 1.3, 0.5]], (len(pos), 1))
+    ins = 0.5 + 0.15 * rng.normal(size=pos.shape) / 2
+    res = {}
+    for mode in ("literal", "factored"):
+        with oracle.arith(mode):
+            t = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float64)
+            p = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float64, mode="plane", pln_o=po, pln_d=pd)
+            s = oracle.trace(rif, rif.shape, ins, vel, h, ds, dtype=np.float64, mode="sdf", sdf=sdf)
+            q = oracle.trace_target(rif, rif.shape, pos, vel, tg, h, ds, dtype=np.float64)
+            b = oracle.backtrace(rif, rif.shape, t["xt"], t["vt"], dx, dv, h, ds, dtype=np.float64)
+            bs = oracle.backtrace(rif, rif.shape, s["xt"], s["vt"], dx, dv, h, ds, dtype=np.float64, sdf=sdf)
+            res[mode] = (t, p, s, q, b, bs)
+    L, F = res["literal"], res["factored"]
+    for k in range(4):
+        assert np.abs(L[k]["xt"] - F[k]["xt"]).max() < 1e-11 and np.abs(L[k]["vt"] - F[k]["vt"]).max() < 1e-11
+    assert np.array_equal(L[0]["steps"], F[0]["steps"]) and L[3]["iters"] == F[3]["iters"]
+    assert np.array_equal(L[1]["failmask"], F[1]["failmask"])
+    assert np.abs(L[3]["dist2"] - F[3]["dist2"]).max() < 1e-11
+    assert cases.rel_l2(F[4]["grad"], L[4]["grad"]) < 1e-10 and L[4]["steps_total"] == F[4]["steps_total"]
+    assert cases.rel_l2(F[5]["grad"], L[5]["grad"]) < 1e-10
+    # cable
+    rres, radius, length = 33, 1.0, 4.0
+    cds = radius / rres / 2
+    prof = np.sqrt(2.0 - np.linspace(0, 1, rres) ** 2)
+    n = 200
+    ang = rng.uniform(0, 2 * np.pi, n); rad = 0.8 * np.sqrt(rng.uniform(0, 1, n))
+    cp = np.stack([radius + rad * np.cos(ang), np.full(n, 0.37 * cds), radius + rad * np.sin(ang)], -1)
+    cv = rng.normal(0, 0.05, (n, 3)); cv[:, 1] = 1; cv /= np.linalg.norm(cv, axis=1, keepdims=True)
+    ctg = np.tile([[radius, 0.75 * length, radius]], (n, 1))
+    out = {}
+    for mode in ("literal", "factored"):
+        with oracle.arith(mode):
+            c = oracle.trace_cable(prof, radius, length, cp, cv, ctg, cds, dtype=np.float64)
+            cb = oracle.backtrace_cable(prof, radius, length, c["xt"], c["vt"], dx[:n], dv[:n], cds, dtype=np.float64)
+            out[mode] = (c, cb)
+    assert np.abs(out["literal"][0]["xt"] - out["factored"][0]["xt"]).max() < 1e-11
+    assert np.abs(out["literal"][0]["dist2"] - out["factored"][0]["dist2"]).max() < 1e-11
+    assert cases.rel_l2(out["factored"][1]["grad"], out["literal"][1]["grad"]) < 1e-10
+
+
+# ------------------------------------------------------------------------------------ edge cases / errors
+def test_oracle_errors_and_edges(oracle):
+    rif = np.ones((8, 8, 8), np.float32)
+    x = np.random.default_rng(0).uniform(0, 7, (10, 3)).astype(np.float32)
+    with pytest.raises(RuntimeError, match="Resolution doesn't match data"):       # src/volume.cpp:37
+        oracle.trace(rif, (8, 8, 9), x, x, 1.0, 0.5)
+    with pytest.raises(RuntimeError, match="invalid resolution"):                  # src/volume.cpp:124
+        oracle.trace(np.ones(8, np.float32), (1, 1, 8), x, x, 1.0, 0.5)
+    e = np.zeros((0, 3), np.float32)
+    assert oracle.trace(rif, rif.shape, e, e, 1.0, 0.5)["xt"].shape == (0, 3)
+    assert np.all(oracle.backtrace(rif, rif.shape, e, e, e, e, 1.0, 0.5)["grad"] == 0)
+    # rays that never enter keep xt = pos, vt = vel (Q6)
+    pos = np.array([[-1.0, 3, 3], [3, 3, 3], [20, 3, 3]], np.float32)
+    vel = np.array([[-1.0, 0, 0], [1, 0, 0], [1, 0, 0]], np.float32)
+    for mode in ("literal", "factored"):
+        with oracle.arith(mode):
+            o = oracle.trace(rif, rif.shape, pos, vel, 1.0, 0.5)
+        assert np.array_equal(o["xt"][0], pos[0]) and np.array_equal(o["xt"][2], pos[2]) and o["xt"][1, 0] == 7.0
+    # max_steps exhaustion: a ray at rest outside the box never satisfies escaped() (needs v != 0): the
+    # loop runs max_steps = int(4*h*max(res)/ds) times and the ray is reported failed (src/tracer.cpp:89-96)
+    p2 = np.array([[-1.0, 3, 3]], np.float32); v2 = np.zeros((1, 3), np.float32)
+    o = oracle.trace(rif, rif.shape, p2, v2, 1.0, 0.5)
+    assert o["n_failed"] == 1 and o["iters"] == int(4 * 1.0 * 8 / 0.5) and np.array_equal(o["xt"], p2)
+    # 1x1x1 volume: constant n, zero gradient (src/volume.cpp:117-121)
+    n1, g1 = oracle.eval_grad(np.array([1.5], np.float32), (1, 1, 1), 1.0, x)
+    assert np.all(n1 == 1.5) and np.all(g1 == 0)
