@@ -19,6 +19,7 @@ FLAG_SORT_RAYS = 1
 FLAG_CORRECTED_H = 2
 FLAG_NO_ZERO = 4
 FLAG_DIRECT_ATOMICS = 8
+FLAG_DEBUG_COUNTERS = 16
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
 
@@ -47,6 +48,8 @@ SIGNATURES = {
     "drrt_backtrace_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
     "drrt_backtrace_sdf_f32": (_i, [_vp, _vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
     "drrt_backtrace_cable_f32": (_i, [_vp, _sz, _f, _f, _sz, _vp, _vp, _vp, _vp, _f, _vp] + _tail),
+    "drrt_last_order": (_vp, [_vp]),
+    "drrt_set_order_hint": (None, [_vp, _sz]),
     "drrt_profile_begin": (_i, [_i]),
     "drrt_profile_collect": (_i, [_vp, _vp, _i]),
     "drrt_profile_end": (None, []),

@@ -43,6 +43,7 @@ struct Vol {
 
 struct Cell {
   int base;             // flat index of corner 000
+  int ix, iy, iz;       // (clamped) integer coordinates of corner 000
   int ox, oy, oz;       // element offsets to the +x, +y, +z neighbours (0 where clamped)
   float wx, wy, wz;     // fractional weights w0 = pm - floor(pm)  (unclamped, Q11)
 };
@@ -72,6 +73,7 @@ DRRT_HD Cell locate(const Vol& V, float px, float py, float pz) {
   int y0 = clampi(iy, 0, V.H - 1), y1 = clampi(iy + 1, 0, V.H - 1);
   int z0 = clampi(iz, 0, V.D - 1), z1 = clampi(iz + 1, 0, V.D - 1);
   c.base = z0 * V.sz + y0 * V.sy + x0;
+  c.ix = x0; c.iy = y0; c.iz = z0;
   c.ox = x1 - x0; c.oy = (y1 - y0) * V.sy; c.oz = (z1 - z0) * V.sz;
   return c;
 }

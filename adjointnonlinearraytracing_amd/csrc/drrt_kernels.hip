@@ -161,6 +161,8 @@ struct BackArgs {
   float ds;
   float grad_scale;            // 1 (as written, Q3) or 1/h (DRRT_FLAG_CORRECTED_H)
   int max_steps;
+  unsigned long long* dbg;     // nullable: [0] window flushes, [1] taps via LDS, [2] taps via global fallback
+  int experiment;              // development ablations (0 = product behaviour)
 };
 
 template <int MODE>
@@ -181,6 +183,275 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
         atomic_add_f32(g + c.oz, w.c001);             atomic_add_f32(g + c.oz + c.ox, w.c101);
         atomic_add_f32(g + c.oz + c.oy, w.c011);      atomic_add_f32(g + c.oz + c.oy + c.ox, w.c111);
       });
+  }
+  block_stats(a.stats, steps, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint march with per-wave LDS gradient windows (the default adjoint kernel)
+//
+// Why: one global fp32 atomic per tap runs at the memory-side atomic rate, and that rate collapses
+// when many lanes hit the same few addresses (measured on MI355X, Luneburg 256^3 / 1M rays: 237 ms
+// for 4.1e9 lane-atomics -- every ray passes through the handful of voxels around the focus).
+// Rays of a wave are spatially coherent (locality sort), so each wave keeps a small box of
+// gradient voxels ("window") in LDS and accumulates its taps there with ds_add_f32; the window is
+// flushed to the global grid -- one atomic per touched voxel, contiguous in x -- only when the
+// rays walk out of it.  Lanes whose cell falls outside the window (incoherent wave, clamped
+// boundary cell) fall back to direct global atomics, so the result never depends on the window.
+//
+//   window      kWinX x kWinY x kWinZ voxels, row pitch kWinPX (odd: z/y strides do not alias LDS banks)
+//   anchor      around the cell of the wave's median contributing lane, shifted towards its
+//               direction of travel (most of the window lies ahead of the rays)
+//   re-anchor   as soon as a contributing lane misses the window (wave-uniform decision); if lanes
+//               still miss afterwards the window stays put for 4 steps (no thrashing)
+//   sync        none across waves: every wave owns its window; all control flow around the
+//               cooperative flush is wave-uniform (ballot / readlane values)
+// ---------------------------------------------------------------------------------------------
+constexpr int kWinX = 12, kWinY = 12, kWinZ = 12;
+constexpr int kWinPX = 13;                                // padded row pitch
+constexpr int kWinSY = kWinPX, kWinSZ = kWinPX * kWinY;   // LDS strides of y and z
+constexpr int kWinFloats = kWinSZ * kWinZ;                // 1872 floats = 7.3 KiB per wave
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): LDS ops of this wave have completed
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Flush the wave's window into the global grid and leave it zeroed.  Called with all 64 lanes.
+__device__ __forceinline__ void win_flush(float* win, int ox, int oy, int oz, float* __restrict__ grad,
+                                          const Vol& V, int lane, bool no_global = false) {
+  wave_lds_fence();
+  for (int k = lane; k < kWinFloats; k += kWave) {
+    // ds_wrxchg_rtn_b32: read the accumulated value and reset the slot in one LDS op
+    float v = __hip_atomic_exchange(&win[k], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (v != 0.f && !no_global) {
+      int lx = k % kWinPX, r = k / kWinPX;
+      int ly = r % kWinY, lz = r / kWinY;
+      atomic_add_f32(grad + ((oz + lz) * V.sz + (oy + ly) * V.sy + (ox + lx)), v);
+    }
+  }
+  wave_lds_fence();
+}
+
+// Per-lane register accumulators for the 8 corners of the cell the ray is currently in.  A ray
+// stays in one cell for ~h/ds steps and neighbouring cells share a face, so the lane sums its own
+// contributions in registers and hands them to the LDS window only when the ray leaves the cell:
+// a move across ONE face emits the 4 corners left behind and carries the 4 shared ones over.
+// This cuts the ds_add_f32 traffic ~4x, and -- just as important -- same-address collisions inside
+// one LDS atomic instruction (rays of a wave share voxels; colliding lanes are serialised by the
+// LDS: measured 18 ms of a 25 ms adjoint) because lanes cross faces at different steps.
+// (kept as plain scalars, not a struct: hipcc otherwise parks the aggregate in scratch memory)
+
+struct WinCtx {
+  float* win; float* grad; int wox, woy, woz; int sy, sz; int experiment;
+};
+
+__device__ __forceinline__ bool win_local(const WinCtx& W, int cx, int cy, int cz, int& lidx) {
+  const int lx = cx - W.wox, ly = cy - W.woy, lz = cz - W.woz;
+  lidx = lz * kWinSZ + ly * kWinSY + lx;
+  return ((unsigned)lx < (unsigned)(kWinX - 1)) & ((unsigned)ly < (unsigned)(kWinY - 1)) &
+         ((unsigned)lz < (unsigned)(kWinZ - 1));
+}
+
+// add all 8 accumulated corners of the lane's cell; returns true when the LDS window took them
+__device__ __forceinline__ bool emit8(const WinCtx& W, int cx, int cy, int cz, int base,
+                                      float a000, float a100, float a010, float a110,
+                                      float a001, float a101, float a011, float a111) {
+  int lidx;
+  const bool inw = win_local(W, cx, cy, cz, lidx);
+  if (inw) {
+    if (W.experiment != 3) {
+      float* q = W.win + lidx;
+      atomicAdd(q, a000);                        atomicAdd(q + 1, a100);
+      atomicAdd(q + kWinSY, a010);               atomicAdd(q + kWinSY + 1, a110);
+      atomicAdd(q + kWinSZ, a001);               atomicAdd(q + kWinSZ + 1, a101);
+      atomicAdd(q + kWinSZ + kWinSY, a011);      atomicAdd(q + kWinSZ + kWinSY + 1, a111);
+    }
+  } else if (W.experiment != 2) {
+    float* g = W.grad + base;
+    atomic_add_f32(g, a000);                     atomic_add_f32(g + 1, a100);
+    atomic_add_f32(g + W.sy, a010);              atomic_add_f32(g + W.sy + 1, a110);
+    atomic_add_f32(g + W.sz, a001);              atomic_add_f32(g + W.sz + 1, a101);
+    atomic_add_f32(g + W.sz + W.sy, a011);       atomic_add_f32(g + W.sz + W.sy + 1, a111);
+  }
+  return inw;
+}
+
+// The ray moved from cell A to the face-adjacent cell (axis 0/1/2, dir +1/-1): emit the face of A
+// that is left behind, carry the shared face over, zero the new far face.  Returns true when the
+// LDS window took the emitted corners.
+__device__ __forceinline__ bool shift_emit4(const WinCtx& W, int cx, int cy, int cz, int base,
+                                            float& a000, float& a100, float& a010, float& a110,
+                                            float& a001, float& a101, float& a011, float& a111,
+                                            int axis, int dir) {
+  const bool ax = axis == 0, ay = axis == 1;
+  // the two faces perpendicular to `axis` (lo: corner bit 0, hi: corner bit 1), in a fixed (p, q) order
+  const float lo0 = ax ? a000 : (ay ? a000 : a000), hi0 = ax ? a100 : (ay ? a010 : a001);
+  const float lo1 = ax ? a010 : (ay ? a100 : a100), hi1 = ax ? a110 : (ay ? a110 : a101);
+  const float lo2 = ax ? a001 : (ay ? a001 : a010), hi2 = ax ? a101 : (ay ? a011 : a011);
+  const float lo3 = ax ? a011 : (ay ? a101 : a110), hi3 = ax ? a111 : (ay ? a111 : a111);
+  const bool fwd = dir > 0;
+  const float e0 = fwd ? lo0 : hi0, e1 = fwd ? lo1 : hi1, e2 = fwd ? lo2 : hi2, e3 = fwd ? lo3 : hi3;   // emitted
+  const float k0 = fwd ? hi0 : lo0, k1 = fwd ? hi1 : lo1, k2 = fwd ? hi2 : lo2, k3 = fwd ? hi3 : lo3;   // carried
+  // LDS / global strides of the in-face directions p (elements 0->1) and q (0->2), and of the axis itself
+  const int lp = ax ? kWinSY : 1, lq = (ax | ay) ? kWinSZ : kWinSY, la = ax ? 1 : (ay ? kWinSY : kWinSZ);
+  const int gp = ax ? W.sy : 1, gq = (ax | ay) ? W.sz : W.sy, ga = ax ? 1 : (ay ? W.sy : W.sz);
+  int lidx;
+  const bool inw = win_local(W, cx, cy, cz, lidx);
+  if (inw) {
+    if (W.experiment != 3) {
+      float* q = W.win + lidx + (fwd ? 0 : la);
+      atomicAdd(q, e0); atomicAdd(q + lp, e1); atomicAdd(q + lq, e2); atomicAdd(q + lq + lp, e3);
+    }
+  } else if (W.experiment != 2) {
+    float* g = W.grad + base + (fwd ? 0 : ga);
+    atomic_add_f32(g, e0); atomic_add_f32(g + gp, e1); atomic_add_f32(g + gq, e2); atomic_add_f32(g + gq + gp, e3);
+  }
+  // new cell: the carried face becomes the near face (lo when moving forward, hi when moving backward)
+  const float n_lo0 = fwd ? k0 : 0.f, n_lo1 = fwd ? k1 : 0.f, n_lo2 = fwd ? k2 : 0.f, n_lo3 = fwd ? k3 : 0.f;
+  const float n_hi0 = fwd ? 0.f : k0, n_hi1 = fwd ? 0.f : k1, n_hi2 = fwd ? 0.f : k2, n_hi3 = fwd ? 0.f : k3;
+  // scatter the faces back (inverse of the gather above)
+  a000 = n_lo0;
+  a100 = ax ? n_hi0 : n_lo1;                       // x: hi0 | y: lo1 | z: lo1
+  a010 = ax ? n_lo1 : (ay ? n_hi0 : n_lo2);        // x: lo1 | y: hi0 | z: lo2
+  a110 = ax ? n_hi1 : (ay ? n_hi1 : n_lo3);        // x: hi1 | y: hi1 | z: lo3
+  a001 = ax ? n_lo2 : (ay ? n_lo2 : n_hi0);        // x: lo2 | y: lo2 | z: hi0
+  a101 = ax ? n_hi2 : (ay ? n_lo3 : n_hi1);        // x: hi2 | y: lo3 | z: hi1
+  a011 = ax ? n_lo3 : (ay ? n_hi2 : n_hi2);        // x: lo3 | y: hi2 | z: hi2
+  a111 = n_hi3;
+  return inw;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
+  __shared__ float s_win[kWavesPerBlock][kWinFloats];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  float* win = s_win[wid];
+  for (int k = lane; k < kWinFloats; k += kWave) win[k] = 0.f;
+  wave_lds_fence();
+
+  const Vol& V = a.vol;
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  AdjState s;
+  s.active = false;
+  if (t < a.n) {
+    const size_t i = a.perm ? (size_t)a.perm[t] : t;
+    Ray3 p = ld3(a.xt, i), u = ld3(a.vt, i), gxv = ld3(a.dx, i), gvv = ld3(a.dv, i);
+    s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
+    adj_init(V, a.ds, gxv.x, gxv.y, gxv.z, gvv.x, gvv.y, gvv.z, s);
+    if (MODE == 1 && s.active) {                                            // src/tracer.cpp:476-477
+      Cell c = locate(V, s.x, s.y, s.z);
+      s.outside = interp<false>(fetch(a.sdf, c), c.wx, c.wy, c.wz).n >= 0.f;
+    }
+  }
+  WinCtx W;
+  W.win = win; W.grad = a.grad; W.sy = V.sy; W.sz = V.sz; W.experiment = a.experiment;
+  // window origin (wave-uniform).  Start far away: nothing is "in the window" before the first anchor.
+  W.wox = W.woy = W.woz = -(1 << 28);
+  bool acc_valid = false;
+  int acx = 0, acy = 0, acz = 0, abase = 0;
+  float a000 = 0.f, a100 = 0.f, a010 = 0.f, a110 = 0.f, a001 = 0.f, a101 = 0.f, a011 = 0.f, a111 = 0.f;
+  bool dirty = false;
+  int cooldown = 0;
+  unsigned steps = 0;
+  unsigned n_flush = 0, n_lds = 0, n_glb = 0;
+  const int experiment = a.experiment;
+
+  for (int it = 0; it < a.max_steps; ++it) {
+    if (!__any(s.active | acc_valid)) break;                                  // wave-uniform exit
+    Cell c; Corners w;
+    c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0;
+    bool contrib = false;
+    if (s.active) {
+      contrib = adj_step<MODE>(V, a.sdf, a.ds, a.grad_scale, s, c, w);
+      if (contrib) ++steps;
+    }
+    // the 8 taps are distinct voxels with the regular strides (no clamped neighbour)
+    const bool regular = (c.ox == 1) & (c.oy == V.sy) & (c.oz == V.sz);
+    int lidx_cur;
+    bool inw = contrib & regular & win_local(W, c.ix, c.iy, c.iz, lidx_cur);
+    const unsigned long long cm = __ballot(contrib & regular);
+    const unsigned long long mm = __ballot(contrib & regular & !inw);
+    if (mm != 0ull && cooldown == 0) {
+      // ---- re-anchor around the cells the rays are in NOW (wave-uniform branch) ----
+      if (dirty) { win_flush(win, W.wox, W.woy, W.woz, a.grad, V, lane, experiment == 2); dirty = false; ++n_flush; }
+      // reference lane: the middle of the contributing lanes (sorted rays => spatial median-ish)
+      const int first = __ffsll((long long)cm) - 1, last = 63 - __clzll((long long)cm);
+      int ref = (first + last) >> 1;
+      if (!((cm >> ref) & 1ull)) ref = first;
+      const int rx = __shfl(c.ix, ref, kWave), ry = __shfl(c.iy, ref, kWave), rz = __shfl(c.iz, ref, kWave);
+      // backward direction of travel of the reference lane: d = -v
+      const float dx_ = -__shfl(s.vx, ref, kWave), dy_ = -__shfl(s.vy, ref, kWave), dz_ = -__shfl(s.vz, ref, kWave);
+      const float dm = fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f));
+      // fraction of the window kept BEHIND the reference cell: 0.1 when moving fast along +axis, 0.9 along -axis
+      // (at least one cell behind: the cell being left still has to emit its far face)
+      const float fx = 0.5f - 0.35f * (dx_ / dm), fy = 0.5f - 0.35f * (dy_ / dm), fz = 0.5f - 0.35f * (dz_ / dm);
+      int ox = rx - (int)(fx * (float)(kWinX - 2));
+      int oy = ry - (int)(fy * (float)(kWinY - 2));
+      int oz = rz - (int)(fz * (float)(kWinZ - 2));
+      ox = max(0, min(ox, V.W - kWinX)); oy = max(0, min(oy, V.H - kWinY)); oz = max(0, min(oz, V.D - kWinZ));
+      W.wox = __builtin_amdgcn_readfirstlane(ox); W.woy = __builtin_amdgcn_readfirstlane(oy);
+      W.woz = __builtin_amdgcn_readfirstlane(oz);
+      inw = contrib & regular & win_local(W, c.ix, c.iy, c.iz, lidx_cur);
+      // lanes still outside (incoherent wave) use global atomics; do not thrash: leave the window
+      // where it is for a few steps before trying again
+      const unsigned long long mm2 = __ballot(contrib & regular & !inw);
+      cooldown = (mm2 != 0ull) ? 4 : 0;
+    } else if (cooldown > 0) {
+      --cooldown;
+    }
+    bool used_lds = false;
+    if (contrib) {
+      if (inw) ++n_lds; else ++n_glb;
+      if (!regular) {
+        // clamped boundary cell: taps coincide; bypass accumulators and window
+        if (acc_valid) { used_lds |= emit8(W, acx, acy, acz, abase, a000, a100, a010, a110, a001, a101, a011, a111); acc_valid = false; }
+        if (experiment != 2 && experiment != 1) {
+          float* g = a.grad + c.base;
+          atomic_add_f32(g, w.c000);                    atomic_add_f32(g + c.ox, w.c100);
+          atomic_add_f32(g + c.oy, w.c010);             atomic_add_f32(g + c.oy + c.ox, w.c110);
+          atomic_add_f32(g + c.oz, w.c001);             atomic_add_f32(g + c.oz + c.ox, w.c101);
+          atomic_add_f32(g + c.oz + c.oy, w.c011);      atomic_add_f32(g + c.oz + c.oy + c.ox, w.c111);
+        }
+      } else {
+        if (acc_valid && c.base != abase) {
+          const int sx = c.ix - acx, sy = c.iy - acy, sz = c.iz - acz;
+          const int nchg = (sx != 0) + (sy != 0) + (sz != 0);
+          const int ssum = sx + sy + sz;
+          if (nchg == 1 && (ssum == 1 || ssum == -1)) {
+            if (experiment != 1) used_lds |= shift_emit4(W, acx, acy, acz, abase, a000, a100, a010, a110, a001, a101, a011, a111,
+                                                             sx != 0 ? 0 : (sy != 0 ? 1 : 2), ssum);
+          } else {
+            if (experiment != 1) used_lds |= emit8(W, acx, acy, acz, abase, a000, a100, a010, a110, a001, a101, a011, a111);
+            a000 = a100 = a010 = a110 = a001 = a101 = a011 = a111 = 0.f;
+          }
+        } else if (!acc_valid) {
+          a000 = a100 = a010 = a110 = a001 = a101 = a011 = a111 = 0.f;
+        }
+        acc_valid = true; acx = c.ix; acy = c.iy; acz = c.iz; abase = c.base;
+        a000 += w.c000; a100 += w.c100; a010 += w.c010; a110 += w.c110;
+        a001 += w.c001; a101 += w.c101; a011 += w.c011; a111 += w.c111;
+      }
+    } else if (acc_valid) {
+      // the ray has ended: hand over what is left
+      if (experiment != 1) used_lds |= emit8(W, acx, acy, acz, abase, a000, a100, a010, a110, a001, a101, a011, a111);
+      acc_valid = false;
+    }
+    dirty = dirty | (__ballot(used_lds) != 0ull);
+  }
+  if (acc_valid && experiment != 1) { if (emit8(W, acx, acy, acz, abase, a000, a100, a010, a110, a001, a101, a011, a111)) dirty = true; }
+  dirty = __ballot(dirty) != 0ull;
+  if (dirty) { win_flush(win, W.wox, W.woy, W.woz, a.grad, V, lane, experiment == 2); ++n_flush; }
+  if (a.dbg) {
+    unsigned f = lane == 0 ? n_flush : 0u;
+    unsigned l = wave_sum_u32(n_lds), g = wave_sum_u32(n_glb);
+    if (lane == 0) {
+      atomicAdd(&a.dbg[0], (unsigned long long)f); atomicAdd(&a.dbg[1], (unsigned long long)l);
+      atomicAdd(&a.dbg[2], (unsigned long long)g);
+    }
   }
   block_stats(a.stats, steps, 0u);
 }
@@ -292,6 +563,18 @@ static int fail_hip(hipError_t e, const char* where) {
 
 extern "C" const char* drrt_last_error(void) { return g_err; }
 
+// ---- visit-order hand-over between paired calls (per host thread) ----------------------------
+static thread_local const uint32_t* g_last_order = nullptr;   // order used by the last sorted call
+static thread_local size_t g_last_order_n = 0;
+static thread_local const uint32_t* g_hint_order = nullptr;   // order to use in the NEXT march call
+static thread_local size_t g_hint_n = 0;
+
+extern "C" const uint32_t* drrt_last_order(size_t* n_out) {
+  if (n_out) *n_out = g_last_order_n;
+  return g_last_order;
+}
+extern "C" void drrt_set_order_hint(const uint32_t* order, size_t n) { g_hint_order = order; g_hint_n = n; }
+
 // ---- optional per-kernel timing (bench / profiling aid; not thread-safe) --------------------
 // Event pairs are recorded on the call's stream right around a kernel launch; nothing
 // synchronises until drrt_profile_collect().
@@ -382,10 +665,16 @@ static int zero_stats(drrt_stats* stats, hipStream_t s) {
 static int maybe_sort(const Vol& V, float h, size_t n, const float* pos, const float* vel, float dir_sign,
                       unsigned flags, void* ws, size_t ws_bytes, const uint32_t** perm, hipStream_t s) {
   *perm = nullptr;
+  // a hint from the caller (normally the paired forward call's order) replaces the sort; it is
+  // consumed by this call whether or not it is usable
+  const uint32_t* hint = g_hint_order; const size_t hint_n = g_hint_n;
+  g_hint_order = nullptr; g_hint_n = 0;
+  if (hint && hint_n == n) { *perm = hint; return DRRT_OK; }
   if (!(flags & DRRT_FLAG_SORT_RAYS) || n < 2) return DRRT_OK;
   if (!ws || ws_bytes < sort_workspace_bytes(n)) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_SORT_RAYS");
   ProfScope prof(DRRT_PROF_SORT, s);
   hipError_t e = sort_rays_by_entry_voxel(V, h, n, pos, vel, dir_sign, ws, ws_bytes, perm, s);
+  if (e == hipSuccess) { g_last_order = *perm; g_last_order_n = n; }
   return e == hipSuccess ? DRRT_OK : fail_hip(e, "sort_rays_by_entry_voxel");
 }
 
@@ -498,9 +787,20 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   a.sdf = sdf; a.xt = xt; a.vt = vt; a.dx = dx; a.dv = dv; a.grad = grad; a.stats = stats;
   a.n = n; a.ds = ds; a.max_steps = steps_adj(h, res, ds);
   a.grad_scale = (flags & DRRT_FLAG_CORRECTED_H) ? a.vol.inv_h : 1.0f;
+  a.experiment = (int)((flags >> 8) & 0xffu);
+  a.dbg = nullptr;
+  if (flags & DRRT_FLAG_DEBUG_COUNTERS) {        // last 64 bytes of the workspace
+    if (!ws || ws_bytes < 512) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_DEBUG_COUNTERS");
+    a.dbg = (unsigned long long*)((char*)ws + ((ws_bytes - 512) & ~(size_t)7));
+    hipError_t e = hipMemsetAsync(a.dbg, 0, 512, s);
+    if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(dbg)");
+  }
   {
     ProfScope prof(DRRT_PROF_BACKTRACE, s);
-    hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    if (flags & DRRT_FLAG_DIRECT_ATOMICS)
+      hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    else
+      hipLaunchKernelGGL(k_backtrace_win<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
   }
   LAUNCH_CHECK("k_backtrace");
   return DRRT_OK;

@@ -1,12 +1,22 @@
 // drrt_sort.hip -- locality sort of rays by entry voxel (device side, rocPRIM radix sort).
 //
 // Not part of the reference (enoki processes rays in caller order, array-at-a-time); this is the
-// MI355X-side answer to SURVEY.md section 7 step 5: lanes of a wave should touch neighbouring
-// voxels so that each of the 8 taps of a wave-step hits a handful of 128-B lines and the adjoint's
-// scatter targets coincide / are contiguous.  Key = flat voxel index (z*H + y)*W + x of the point
-// where the ray first meets the grid box along its march direction (the ray's own position when it
-// starts inside).  The permutation only changes the VISIT order; results are written back in the
-// caller's ray order.
+// MI355X-side answer to SURVEY.md section 7 step 5: the 64 rays of a wave should stay spatially
+// close for their WHOLE march, so that each of the 8 taps of a wave-step hits a handful of 128-B
+// lines and the adjoint's scatter targets fall into the wave's LDS gradient window.
+//
+// Key = 60-bit "light-field Z-order": the straight line through the ray (from where it meets the
+// grid box along its march direction to where that line leaves the box again) is described by its
+// two end points, each quantised to 10 bits per axis, and the 6 coordinates are bit-interleaved
+// (Morton order in 6-D).  Consecutive keys are therefore close at BOTH ends of the chord:
+//   * plane sources: both end points form 2-D patches  -> compact ray bundles;
+//   * the adjoint of a focusing lens starts with thousands of rays in ONE voxel pointing in
+//     different directions: the far end of the chord separates them by direction;
+//   * point / cone sources: the near end is degenerate, the far end orders the fan.
+// (A key on the start voxel alone -- the first version -- left 27 % of the adjoint's taps outside
+// the LDS windows on the Luneburg benchmark: strips of rays on the side faces fan out.)
+// For the adjoint the march direction is -vt and the "start" is the recorded exit sample xt.
+// The permutation only changes the VISIT order; results are written back in the caller's ray order.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
@@ -15,9 +25,12 @@
 
 namespace drrt {
 
-__global__ void __launch_bounds__(256) k_entry_keys(Vol V, size_t n, const float* __restrict__ pos,
+constexpr int kKeyBitsPerAxis = 10;
+constexpr int kKeyBits = 6 * kKeyBitsPerAxis;
+
+__global__ void __launch_bounds__(256) k_chord_keys(Vol V, size_t n, const float* __restrict__ pos,
                                                     const float* __restrict__ vel, float dir_sign,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
@@ -36,16 +49,25 @@ __global__ void __launch_bounds__(256) k_entry_keys(Vol V, size_t n, const float
       hit = false;
     }
   }
-  float t = (hit && tmax >= tmin) ? tmin : 0.f;
-  const int r[3] = {V.W, V.H, V.D};
-  int v[3];
+  hit = hit && tmax >= tmin;
+  const float t0 = hit ? tmin : 0.f, t1 = hit ? tmax : 0.f;
+  uint32_t q[6];
+  const float scale = (float)(1 << kKeyBitsPerAxis);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    float e = fmaf(t, d[a], p[a]);
-    e = fminf(fmaxf(e, 0.f), b[a]);
-    v[a] = clampi((int)floorf(e * V.inv_h), 0, r[a] - 1);
+    float inv_b = b[a] > 0.f ? 1.f / b[a] : 0.f;
+    float e0 = fminf(fmaxf(fmaf(t0, d[a], p[a]) * inv_b, 0.f), 0.99999f);
+    float e1 = fminf(fmaxf(fmaf(t1, d[a], p[a]) * inv_b, 0.f), 0.99999f);
+    q[a] = (uint32_t)(e0 * scale);
+    q[3 + a] = (uint32_t)(e1 * scale);
   }
-  keys[i] = (uint32_t)((v[2] * V.H + v[1]) * V.W + v[0]);
+  uint64_t key = 0;
+#pragma unroll
+  for (int bit = 0; bit < kKeyBitsPerAxis; ++bit)
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      key |= (uint64_t)((q[j] >> bit) & 1u) << (6 * bit + (5 - j));
+  keys[i] = key;
   idx[i] = (uint32_t)i;
 }
 
@@ -53,39 +75,38 @@ static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 static size_t cub_temp_bytes(size_t n) {
   size_t temp = 0;
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 32,
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, kKeyBits,
                                                    (hipStream_t)0);
   if (e != hipSuccess || temp == 0) {   // no device visible (CPU-only import): conservative bound
     (void)hipGetLastError();
-    temp = n * 16 + (1u << 20);
+    temp = n * 32 + (1u << 20);
   }
   return temp;
 }
 
-size_t sort_workspace_bytes(size_t n) { return 4 * al(n * sizeof(uint32_t)) + al(cub_temp_bytes(n)); }
+size_t sort_workspace_bytes(size_t n) {
+  return 2 * al(n * sizeof(uint64_t)) + 2 * al(n * sizeof(uint32_t)) + al(cub_temp_bytes(n));
+}
 
 hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const float* pos, const float* vel,
                                     float dir_sign, void* ws, size_t ws_bytes, const uint32_t** perm_out,
                                     hipStream_t stream) {
   (void)h;
   char* base = (char*)ws;
-  const size_t arr = al(n * sizeof(uint32_t));
-  uint32_t* keys_in = (uint32_t*)(base);
-  uint32_t* keys_out = (uint32_t*)(base + arr);
-  uint32_t* idx_in = (uint32_t*)(base + 2 * arr);
-  uint32_t* idx_out = (uint32_t*)(base + 3 * arr);
-  void* temp = base + 4 * arr;
-  size_t temp_bytes = ws_bytes - 4 * arr;
-  hipLaunchKernelGGL(k_entry_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, V, n, pos, vel,
+  const size_t k8 = al(n * sizeof(uint64_t)), k4 = al(n * sizeof(uint32_t));
+  uint64_t* keys_in = (uint64_t*)(base);
+  uint64_t* keys_out = (uint64_t*)(base + k8);
+  uint32_t* idx_in = (uint32_t*)(base + 2 * k8);
+  uint32_t* idx_out = (uint32_t*)(base + 2 * k8 + k4);
+  void* temp = base + 2 * k8 + 2 * k4;
+  size_t temp_bytes = ws_bytes - (2 * k8 + 2 * k4);
+  hipLaunchKernelGGL(k_chord_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, V, n, pos, vel,
                      dir_sign, keys_in, idx_in);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  long long nvox = (long long)V.W * V.H * V.D;
-  int bits = 1;
-  while (bits < 32 && (1LL << bits) < nvox) ++bits;
-  e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t*)keys_in, keys_out,
-                                         (const uint32_t*)idx_in, idx_out, (int)n, 0, bits, stream);
+  e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint64_t*)keys_in, keys_out,
+                                         (const uint32_t*)idx_in, idx_out, (int)n, 0, kKeyBits, stream);
   *perm_out = idx_out;
   return e;
 }

@@ -38,6 +38,12 @@ options = Options()
 # last call's statistics (ray_steps, n_failed, iters) as a device tensor of 3 int64 words
 last_stats: Optional[torch.Tensor] = None
 
+# visit order (int32 ray indices) used by the last SORTED forward call -- a private copy, so it
+# survives later calls that reuse the workspace.  tracer.Back*TracerC keep it on ctx and hand it
+# to the paired backtrace (drrt_set_order_hint): the adjoint then visits rays in the forward's
+# bundle order (see include/drrt_hip.h, "visit order hand-over").
+last_order: Optional[torch.Tensor] = None
+
 _workspaces: Dict[torch.device, torch.Tensor] = {}
 
 
@@ -101,6 +107,27 @@ def read_stats(stats: Optional[torch.Tensor] = None) -> Dict[str, int]:
     return dict(ray_steps=int(s[0]), n_failed=int(s[1]), iters=int(s[2]) & 0xFFFFFFFF)
 
 
+def _capture_order(n: int, device: torch.device) -> None:
+    """Copy the permutation the library just left in the workspace (device-to-device, async)."""
+    global last_order
+    last_order = None
+    if not options.sort_rays or n < 2:
+        return
+    cnt = C.c_size_t(0)
+    ptr = _lib.load().drrt_last_order(C.byref(cnt))
+    if not ptr or cnt.value != n:
+        return
+    ws = _workspaces[device]
+    off = int(ptr) - ws.data_ptr()
+    if 0 <= off and off + 4 * n <= ws.numel():
+        last_order = ws[off:off + 4 * n].view(torch.int32).clone()
+
+
+def _hint(order: Optional[torch.Tensor], n: int) -> None:
+    if order is not None and order.numel() == n and order.dtype == torch.int32 and order.is_cuda:
+        _lib.load().drrt_set_order_hint(C.c_void_p(order.data_ptr()), n)
+
+
 def _warn_failed(stats: torch.Tensor) -> None:
     if options.check_failed and int(stats[1].item()) > 0:
         print("failed to exit all rays")            # src/tracer.cpp:90
@@ -127,6 +154,7 @@ class TracerC:
             _lib.check(_lib.load().drrt_trace_f32(
                 _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), float(h), float(ds),
                 _p(xt), _p(vt), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+            _capture_order(n, dev)
             _warn_failed(st)
         return xt, vt
 
@@ -145,6 +173,7 @@ class TracerC:
                 _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), _p(po), _p(pd),
                 float(h), float(ds), _p(xt), _p(vt), _p(fm), _p(st), _p(ws), ws.numel(), fl,
                 _stream(dev)))
+            _capture_order(n, dev)
             _warn_failed(st)
         return xt, vt, fm
 
@@ -163,6 +192,7 @@ class TracerC:
                 _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), _p(tg),
                 float(h), float(ds), _p(xt), _p(vt), _p(d2), _p(st), _p(ws), ws.numel(), fl,
                 _stream(dev)))
+            _capture_order(n, dev)
             _warn_failed(st)
         return xt, vt, d2
 
@@ -182,6 +212,7 @@ class TracerC:
             _lib.check(_lib.load().drrt_trace_sdf_f32(
                 _p(rif_), _p(sdf_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_),
                 float(h), float(ds), _p(xt), _p(vt), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+            _capture_order(n, dev)
         return xt, vt
 
     def trace_cable(self, rif, radius, length, pos, vel, target, ds):
@@ -201,8 +232,9 @@ class TracerC:
         return xt, vt, d2
 
     # ---- adjoint ------------------------------------------------------------------------
-    def backtrace(self, rif, res, xt, vt, dx, dv, h, ds) -> torch.Tensor:
-        """Tracer::backtrace, src/tracer.cpp:384-440 -> flat dL/dn (fp32[nvox])."""
+    def backtrace(self, rif, res, xt, vt, dx, dv, h, ds, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Tracer::backtrace, src/tracer.cpp:384-440 -> flat dL/dn (fp32[nvox]).
+        `order` (optional, not in the reference): visit order of the paired forward call."""
         dev = _dev(rif)
         with torch.cuda.device(dev):
             rif_, xt_ = _f32(rif, dev).reshape(-1), _rays(xt, dev)
@@ -211,12 +243,13 @@ class TracerC:
             grad = torch.empty_like(rif_)
             fl = _flags(adjoint=True)
             ws, st = _workspace(n, fl, dev), _new_stats(dev)
+            _hint(order, n)
             _lib.check(_lib.load().drrt_backtrace_f32(
                 _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
                 float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
         return grad
 
-    def backtrace_sdf(self, rif, sdf, res, xt, vt, dx, dv, h, ds) -> torch.Tensor:
+    def backtrace_sdf(self, rif, sdf, res, xt, vt, dx, dv, h, ds, order: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Tracer::backtrace_sdf, src/tracer.cpp:443-509."""
         dev = _dev(rif)
         with torch.cuda.device(dev):
@@ -229,6 +262,7 @@ class TracerC:
             grad = torch.empty_like(rif_)
             fl = _flags(adjoint=True)
             ws, st = _workspace(n, fl, dev), _new_stats(dev)
+            _hint(order, n)
             _lib.check(_lib.load().drrt_backtrace_sdf_f32(
                 _p(rif_), _p(sdf_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
                 float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))

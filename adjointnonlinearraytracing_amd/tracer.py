@@ -29,12 +29,13 @@ class BackTracerC(torch.autograd.Function):
         ctx.rif = rif.detach().flatten()
         ctx.h, ctx.ds = h, ds
         ctx.outx, ctx.outv = drrt.TracerC().trace(ctx.rif, ctx.shape, x.detach(), v.detach(), h, ds)
+        ctx.order = drrt.last_order          # the adjoint visits rays in the forward's bundle order
         return ctx.outx.clone(), ctx.outv.clone()
 
     @staticmethod
     def backward(ctx, grad_x, grad_v):
         drif = drrt.TracerC().backtrace(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v,
-                                        ctx.h, ctx.ds).reshape(*ctx.shape)
+                                        ctx.h, ctx.ds, order=ctx.order).reshape(*ctx.shape)
         return drif, None, None, None, None
 
 
@@ -48,6 +49,7 @@ class BackPlaneTracerC(torch.autograd.Function):
         ctx.h, ctx.ds = h, ds
         ctx.outx, ctx.outv, outmask = drrt.TracerC().trace_pln(
             ctx.rif, ctx.shape, x.detach(), v.detach(), sp.detach(), sn.detach(), h, ds)
+        ctx.order = drrt.last_order
         outmask = outmask.to(torch.bool)
         ctx.mark_non_differentiable(outmask)
         return ctx.outx.clone(), ctx.outv.clone(), outmask
@@ -58,7 +60,7 @@ class BackPlaneTracerC(torch.autograd.Function):
             grad_x = grad_x.clone()
             grad_x[outmask] = 0
         drif = drrt.TracerC().backtrace(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v,
-                                        ctx.h, ctx.ds).reshape(*ctx.shape)
+                                        ctx.h, ctx.ds, order=ctx.order).reshape(*ctx.shape)
         return drif, None, None, None, None, None, None
 
 
@@ -72,12 +74,13 @@ class BackTargetTracerC(torch.autograd.Function):
         ctx.h, ctx.ds = h, ds
         ctx.outx, ctx.outv, dist2 = drrt.TracerC().trace_target(
             ctx.rif, ctx.shape, x.detach(), v.detach(), sp.detach(), h, ds)
+        ctx.order = drrt.last_order
         return ctx.outx.clone(), ctx.outv.clone(), dist2
 
     @staticmethod
     def backward(ctx, grad_x, grad_v, outdist):
         drif = drrt.TracerC().backtrace(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v,
-                                        ctx.h, ctx.ds).reshape(*ctx.shape)
+                                        ctx.h, ctx.ds, order=ctx.order).reshape(*ctx.shape)
         return drif, None, None, None, None, None
 
 
@@ -92,12 +95,13 @@ class BackSDFTracerC(torch.autograd.Function):
         ctx.h, ctx.ds = h, ds
         ctx.outx, ctx.outv = drrt.TracerC().trace_sdf(ctx.rif, ctx.sdf, ctx.shape, x.detach(),
                                                       v.detach(), h, ds)
+        ctx.order = drrt.last_order
         return ctx.outx.clone(), ctx.outv.clone()
 
     @staticmethod
     def backward(ctx, grad_x, grad_v):
         drif = drrt.TracerC().backtrace_sdf(ctx.rif, ctx.sdf, ctx.shape, ctx.outx, ctx.outv,
-                                            grad_x, grad_v, ctx.h, ctx.ds).reshape(*ctx.shape)
+                                            grad_x, grad_v, ctx.h, ctx.ds, order=ctx.order).reshape(*ctx.shape)
         return drif, None, None, None, None, None
 
 

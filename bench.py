@@ -99,7 +99,11 @@ def main():
     ap.add_argument("--rays", type=int, default=1024 * 1024, help="rays per GPU (perfect square)")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--direct-atomics", action="store_true")
+    ap.add_argument("--no-order-reuse", action="store_true",
+                    help="adjoint computes its own visit order instead of reusing the forward's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-counters", action="store_true", help="print LDS-window counters (stderr)")
+    ap.add_argument("--experiment", type=int, default=0, help="development ablation id (0 = product)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -124,7 +128,8 @@ def main():
     res = (C.c_int * 3)(R, R, R)
     flags = 0 if args.no_sort else _lib.FLAG_SORT_RAYS
     aflags = flags | (_lib.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0)
-    ws = torch.empty(int(lib.drrt_workspace_bytes(n, flags)) + 256, dtype=torch.uint8, device=dev)
+    aflags |= (_lib.FLAG_DEBUG_COUNTERS if args.debug_counters else 0) | ((args.experiment & 0xff) << 8)
+    ws = torch.empty(int(lib.drrt_workspace_bytes(n, flags)) + 1024, dtype=torch.uint8, device=dev)
     xt, vt = torch.empty_like(pos), torch.empty_like(vel)
     dx, dv = torch.ones_like(pos), torch.ones_like(vel)          # adjoint seed dx=dv=1 (src/test.cpp:142-144)
     grad = torch.empty(nvox, dtype=torch.float32, device=dev)
@@ -136,6 +141,8 @@ def main():
     def step():
         _lib.check(lib.drrt_trace_f32(p(rif), nvox, res, n, p(pos), p(vel), h, ds, p(xt), p(vt),
                                       p(st_f), p(ws), ws.numel(), flags, stream))
+        if flags and not args.no_order_reuse:        # adjoint visits rays in the forward's bundle order
+            lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
         _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),
                                           p(st_a), p(ws), ws.numel(), aflags, stream))
         if world > 1:
@@ -158,6 +165,14 @@ def main():
     prof = _lib.profile_collect()
     lib.drrt_profile_end()
 
+    if args.debug_counters:
+        off = (ws.numel() - 512) & ~7
+        dbg = ws[off:off + 512].view(torch.int64).cpu().tolist()
+        if args.experiment == 9:
+            print(f"[debug] non-regular {dbg[3]}; misses per 32-iteration bucket {dbg[8:24]}; "
+                  f"wave bbox extent histogram (voxels, every 16th step) {dbg[24:56]}", file=sys.stderr)
+        print(f"[debug] window flushes {dbg[0]}, ray-steps via LDS window {dbg[1]}, via global fallback {dbg[2]}",
+              file=sys.stderr)
     fwd_steps = int(st_f[0].item()); adj_steps = int(st_a[0].item())
     n_failed = int(st_f[1].item())
     t = torch.tensor([elapsed, float(fwd_steps), float(adj_steps)], dtype=torch.float64, device=dev)

@@ -60,6 +60,12 @@ extern "C" {
 #define DRRT_FLAG_DIRECT_ATOMICS 8u /* adjoint only: bypass the LDS gradient windows and issue
                                        one global atomic per tap (debug / A-B measurement)        */
 
+#define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
+                                       written to the last 512 bytes of the workspace:
+                                       [0] LDS-window flushes, [1] ray-steps accumulated through
+                                       the LDS window, [2] ray-steps that fell back to global atomics.
+                                       Bits 8..15 of `flags` select development ablations (0 = product) */
+
 typedef struct drrt_stats {
   unsigned long long ray_steps;  /* sum over rays of march iterations executed while the ray was live */
   unsigned long long n_failed;   /* rays still live after max_steps                                  */
@@ -75,6 +81,19 @@ DRRT_API const char* drrt_last_error(void);
 
 /* Library / build identification, e.g. "drrt_hip 0.1 gfx950". */
 DRRT_API const char* drrt_version(void);
+
+/* ---- visit order hand-over (optimisation hint; results never depend on it) -------------------
+ * A sorted call (DRRT_FLAG_SORT_RAYS) leaves the permutation it used -- n uint32 ray indices, in
+ * visit order -- inside the caller's workspace; drrt_last_order() returns that device pointer
+ * (valid until the workspace is overwritten) and its length.
+ * drrt_set_order_hint(order, n) makes the NEXT march call on this host thread visit its rays in
+ * `order` instead of sorting (consumed by that call; ignored if its ray count differs).
+ * Intended pairing: the adjoint of a forward march (core/tracer.py:294-335 couples them through
+ * ctx.outx/ctx.outv) reuses the forward's order -- rays that entered the grid together stay
+ * together through any smooth medium, which keeps each wave inside its LDS gradient window even
+ * where the exit rays alone (a focus, a caustic) say nothing about the bundle they came from.   */
+DRRT_API const uint32_t* drrt_last_order(size_t* n_out);
+DRRT_API void drrt_set_order_hint(const uint32_t* order, size_t n);
 
 /* ---- forward marches ------------------------------------------------------------------- */
 

@@ -66,8 +66,9 @@ def test_python_mirrors_have_reference_call_shapes(lib):
     assert params(drrt.TracerC.trace_target) == ["rif", "res", "pos", "vel", "target", "h", "ds"]
     assert params(drrt.TracerC.trace_sdf) == ["rif", "sdf", "res", "pos", "vel", "h", "ds"]
     assert params(drrt.TracerC.trace_cable) == ["rif", "radius", "length", "pos", "vel", "target", "ds"]
-    assert params(drrt.TracerC.backtrace) == ["rif", "res", "xt", "vt", "dx", "dv", "h", "ds"]
-    assert params(drrt.TracerC.backtrace_sdf) == ["rif", "sdf", "res", "xt", "vt", "dx", "dv", "h", "ds"]
+    # (+ one optional keyword the reference does not have: the paired forward call's visit order)
+    assert params(drrt.TracerC.backtrace) == ["rif", "res", "xt", "vt", "dx", "dv", "h", "ds", "order"]
+    assert params(drrt.TracerC.backtrace_sdf) == ["rif", "sdf", "res", "xt", "vt", "dx", "dv", "h", "ds", "order"]
     assert params(drrt.TracerC.backtrace_cable) == ["rif", "radius", "length", "xt", "vt", "dx", "dv", "ds"]
     # core/tracer.py:294-526 forward signatures
     assert params(tracer.BackTracerC.forward) == ["rif", "x", "v", "h", "ds"]
