@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
 // rays walk out of it.  Lanes whose cell falls outside the window (incoherent wave, clamped
 // boundary cell) fall back to direct global atomics, so the result never depends on the window.
 //
-//   window      kWinX x kWinY x kWinZ voxels, row pitch kWinPX (odd: z/y strides do not alias LDS banks)
+//   window      kWinX x kWinY x kWinZ voxels of double accumulators, row pitch kWinPX (odd)
 //   anchor      around the cell of the wave's median contributing lane, shifted towards its
 //               direction of travel (most of the window lies ahead of the rays)
 //   re-anchor   as soon as a contributing lane misses the window (wave-uniform decision); if lanes
@@ -207,10 +207,16 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
 //   sync        none across waves: every wave owns its window; all control flow around the
 //               cooperative flush is wave-uniform (ballot / readlane values)
 // ---------------------------------------------------------------------------------------------
-constexpr int kWinX = 12, kWinY = 12, kWinZ = 12;
-constexpr int kWinPX = 13;                                // padded row pitch
+// Accumulators are DOUBLES: measured on gfx950 (tools/lds_atomic_bench.hip) ds_add_f32 costs ~193
+// cycles per wave-instruction per CU even without address collisions (~3 cycles per lane), while
+// ds_add_f64 costs ~8 (ds_add_u32 4.4); collisions add ~12 cycles per colliding lane for f64.  The
+// window sums are therefore also more accurate than fp32 atomics; they are rounded to fp32 once,
+// when the window is flushed into the fp32 grid.
+typedef double win_t;
+constexpr int kWinX = 10, kWinY = 10, kWinZ = 10;
+constexpr int kWinPX = 11;                                // padded row pitch
 constexpr int kWinSY = kWinPX, kWinSZ = kWinPX * kWinY;   // LDS strides of y and z
-constexpr int kWinFloats = kWinSZ * kWinZ;                // 1872 floats = 7.3 KiB per wave
+constexpr int kWinFloats = kWinSZ * kWinZ;                // 1100 slots = 8.6 KiB per wave
 constexpr int kWavesPerBlock = kBlock / kWave;
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -221,16 +227,16 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // Flush the wave's window into the global grid and leave it zeroed.  Called with all 64 lanes.
-__device__ __forceinline__ void win_flush(float* win, int ox, int oy, int oz, float* __restrict__ grad,
+__device__ __forceinline__ void win_flush(win_t* win, int ox, int oy, int oz, float* __restrict__ grad,
                                           const Vol& V, int lane, bool no_global = false) {
   wave_lds_fence();
   for (int k = lane; k < kWinFloats; k += kWave) {
-    // ds_wrxchg_rtn_b32: read the accumulated value and reset the slot in one LDS op
-    float v = __hip_atomic_exchange(&win[k], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (v != 0.f && !no_global) {
+    // ds_wrxchg_rtn_b64: read the accumulated value and reset the slot in one LDS op
+    win_t v = __hip_atomic_exchange(&win[k], (win_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (v != (win_t)0 && !no_global) {
       int lx = k % kWinPX, r = k / kWinPX;
       int ly = r % kWinY, lz = r / kWinY;
-      atomic_add_f32(grad + ((oz + lz) * V.sz + (oy + ly) * V.sy + (ox + lx)), v);
+      atomic_add_f32(grad + ((oz + lz) * V.sz + (oy + ly) * V.sy + (ox + lx)), (float)v);
     }
   }
   wave_lds_fence();
@@ -246,7 +252,7 @@ __device__ __forceinline__ void win_flush(float* win, int ox, int oy, int oz, fl
 // (kept as plain scalars, not a struct: hipcc otherwise parks the aggregate in scratch memory)
 
 struct WinCtx {
-  float* win; float* grad; int wox, woy, woz; int sy, sz; int experiment;
+  win_t* win; float* grad; int wox, woy, woz; int sy, sz; int experiment;
 };
 
 __device__ __forceinline__ bool win_local(const WinCtx& W, int cx, int cy, int cz, int& lidx) {
@@ -264,11 +270,11 @@ __device__ __forceinline__ bool emit8(const WinCtx& W, int cx, int cy, int cz, i
   const bool inw = win_local(W, cx, cy, cz, lidx);
   if (inw) {
     if (W.experiment != 3) {
-      float* q = W.win + lidx;
-      atomicAdd(q, a000);                        atomicAdd(q + 1, a100);
-      atomicAdd(q + kWinSY, a010);               atomicAdd(q + kWinSY + 1, a110);
-      atomicAdd(q + kWinSZ, a001);               atomicAdd(q + kWinSZ + 1, a101);
-      atomicAdd(q + kWinSZ + kWinSY, a011);      atomicAdd(q + kWinSZ + kWinSY + 1, a111);
+      win_t* q = W.win + lidx;
+      atomicAdd(q, (win_t)a000);                        atomicAdd(q + 1, (win_t)a100);
+      atomicAdd(q + kWinSY, (win_t)a010);               atomicAdd(q + kWinSY + 1, (win_t)a110);
+      atomicAdd(q + kWinSZ, (win_t)a001);               atomicAdd(q + kWinSZ + 1, (win_t)a101);
+      atomicAdd(q + kWinSZ + kWinSY, (win_t)a011);      atomicAdd(q + kWinSZ + kWinSY + 1, (win_t)a111);
     }
   } else if (W.experiment != 2) {
     float* g = W.grad + base;
@@ -303,8 +309,9 @@ __device__ __forceinline__ bool shift_emit4(const WinCtx& W, int cx, int cy, int
   const bool inw = win_local(W, cx, cy, cz, lidx);
   if (inw) {
     if (W.experiment != 3) {
-      float* q = W.win + lidx + (fwd ? 0 : la);
-      atomicAdd(q, e0); atomicAdd(q + lp, e1); atomicAdd(q + lq, e2); atomicAdd(q + lq + lp, e3);
+      win_t* q = W.win + lidx + (fwd ? 0 : la);
+      atomicAdd(q, (win_t)e0); atomicAdd(q + lp, (win_t)e1); atomicAdd(q + lq, (win_t)e2);
+      atomicAdd(q + lq + lp, (win_t)e3);
     }
   } else if (W.experiment != 2) {
     float* g = W.grad + base + (fwd ? 0 : ga);
@@ -327,10 +334,10 @@ __device__ __forceinline__ bool shift_emit4(const WinCtx& W, int cx, int cy, int
 
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
-  __shared__ float s_win[kWavesPerBlock][kWinFloats];
+  __shared__ win_t s_win[kWavesPerBlock][kWinFloats];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  float* win = s_win[wid];
-  for (int k = lane; k < kWinFloats; k += kWave) win[k] = 0.f;
+  win_t* win = s_win[wid];
+  for (int k = lane; k < kWinFloats; k += kWave) win[k] = (win_t)0;
   wave_lds_fence();
 
   const Vol& V = a.vol;

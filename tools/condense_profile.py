@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_bench.sh output directory (gpurun_out/prof_<tag>/) into small, committed
+summaries under profiles/: <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, top kernels),
+<tag>_pmc.json (per-kernel averages of every collected counter + derived HBM traffic per launch)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1]
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name if len(name) < 110 else name[:107] + "..."
+
+
+stats = glob.glob(f"{src}/trace/runc/*_kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows[:10]:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"]])
+
+pmc = collections.defaultdict(dict)
+for f in glob.glob(f"{src}/pmc_*/runc/*_counter_collection.csv"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if "drrt::" not in r["Kernel_Name"]:
+            continue
+        kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[kn]["_VGPR"] = [float(r["VGPR_Count"])]
+        agg[kn]["_LDS_bytes_per_block"] = [float(r["LDS_Block_Size"])]
+    for kn, c in agg.items():
+        for k, v in c.items():
+            pmc[kn][k] = sum(v) / len(v)
+for kn, c in pmc.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE
+        # counts 64 B per 128-B request for wide coalesced streams (x2 correction); scattered dword gathers are
+        # uncalibrated, so both the raw and the x2-corrected read figure are kept.
+        c["hbm_read_bytes_raw"] = c["FETCH_SIZE"] * 1024
+        c["hbm_read_bytes_x2"] = c["FETCH_SIZE"] * 2048
+        c["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+        c["hbm_traffic_bytes_per_launch"] = c["hbm_read_bytes_x2"] + c["hbm_write_bytes"]
+json.dump(pmc, open(f"profiles/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
+for b in glob.glob(f"{src}/bench_trace.json"):
+    open(f"profiles/{tag}_bench_under_rocprof.json", "w").write(open(b).read())
+print(json.dumps({k: {kk: round(vv, 1) for kk, vv in v.items() if kk.startswith("hbm") or kk in ("FETCH_SIZE", "WRITE_SIZE")}
+                  for k, v in pmc.items()}, indent=1))

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Profiles `bench.py` on the GPU box: (1) kernel trace + stats, (2)-(4) PMC passes (separate runs, as
+# MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass).  Outputs under
+# gpurun_out/prof_$1/ ; condense with tools/condense_profile.py into profiles/.
+tag=${1:-run}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B > $out/bench_trace.json 2> $out/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- $B > $out/bench_fetch.json 2> $out/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- $B > $out/bench_write.json 2> $out/write.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $out/pmc_sq -- $B > $out/bench_sq.json 2> $out/sq.err
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $out/pmc_tcc -- $B > $out/bench_tcc.json 2> $out/tcc.err
+find $out -name "*.csv" | head -30
+tail -2 $out/*.err | cut -c1-200
