@@ -63,6 +63,24 @@ def make_workload(R: int, n_rays: int, device, seed: int):
     return rif, pos.to(device), vel.to(device), h, ds
 
 
+def measured_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel, from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc.json, produced by tools/profile_bench.sh + tools/condense_profile.py on the SAME
+    command: separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no summary matches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime)
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and "hbm_traffic_bytes_per_launch" in v:
+                return {"bytes": v["hbm_traffic_bytes_per_launch"], "source": os.path.basename(f)}
+    return None
+
+
 def cpu_baseline(R, h, ds, rif_np, pos_np, vel_np, target_seconds=15.0):
     """Time the CPU oracle (kind 'port': plain-C restatement of the reference, single thread --
     the reference's CPU path is single-threaded) on a ray sub-sample."""
@@ -190,6 +208,10 @@ def main():
         ms_fwd, ms_adj, ms_sort, ms_zero = avg("trace"), avg("backtrace"), avg("sort"), avg("zero")
         ach_adj = adj_steps * B_ADJ / (ms_adj * 1e-3) / 1e9
         ach_fwd = fwd_steps * B_FWD / (ms_fwd * 1e-3) / 1e9
+        default_cfg = (R == 256 and n == 1024 * 1024 and not args.no_sort and not args.direct_atomics
+                       and not args.experiment)
+        tr_adj = measured_traffic("drrt::k_backtrace_win") if default_cfg else None
+        tr_fwd = measured_traffic("drrt::k_trace") if default_cfg else None
         out = {
             "metric": "ray-steps/sec (fwd+adjoint), 256^3 RIF grid, 1M rays x 512 steps",
             "value": fwd_total * args.steps / elapsed,
@@ -205,11 +227,13 @@ def main():
                        "adj_ray_steps_per_gpu": adj_steps, "n_failed": n_failed,
                        "sort_rays": not args.no_sort, "parallelism": f"ray-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "adjoint march (k_backtrace)", "achieved": ach_adj,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_adj / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_adj / HBM_PEAK_GBS, "traffic": tr_adj and tr_adj["bytes"],
+                         "traffic_source": tr_adj and tr_adj["source"],
                          "algorithmic_bytes_per_ray_step": B_ADJ, "ray_steps_per_launch": adj_steps,
                          "avg_kernel_ms": ms_adj},
             "roofline_fwd": {"bound": "hbm", "kernel": "forward march (k_trace)", "achieved": ach_fwd,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_fwd / HBM_PEAK_GBS, "traffic": None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_fwd / HBM_PEAK_GBS, "traffic": tr_fwd and tr_fwd["bytes"],
+                             "traffic_source": tr_fwd and tr_fwd["source"],
                              "algorithmic_bytes_per_ray_step": B_FWD, "ray_steps_per_launch": fwd_steps,
                              "avg_kernel_ms": ms_fwd},
             "phase_ms": {"sort_avg": ms_sort, "zero_grid": ms_zero, "trace": ms_fwd, "backtrace": ms_adj},
