@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
     }
     bool used_lds = false;
     if (contrib) {
-      if (inw) ++n_lds; else ++n_glb;
+      if (a.dbg) { if (inw) ++n_lds; else ++n_glb; }
       if (!regular) {
         // clamped boundary cell: taps coincide; bypass accumulators and window
         if (acc_valid) { used_lds |= emit8(W, acx, acy, acz, abase, a000, a100, a010, a110, a001, a101, a011, a111); acc_valid = false; }
@@ -648,7 +648,9 @@ static int make_vol(const float* rif, long long nvox, const int res[3], float h,
     return fail(DRRT_ERR_RES_MISMATCH, "Resolution doesn't match data");
   if (!(res[0] == 1 && res[1] == 1 && res[2] == 1) && (res[0] < 2 || res[1] < 2))
     return fail(DRRT_ERR_BAD_RES, "volume: invalid resolution!");
-  if (nvox > 0x7fffffffLL) return fail(DRRT_ERR_ARG, "grid too large for int32 indexing");
+  if (nvox >= (1LL << 29)) return fail(DRRT_ERR_ARG, "grid too large (>= 2^29 voxels) for 32-bit byte offsets");
+  if (res[0] >= (1 << 24) || res[1] >= (1 << 24) || res[2] >= (1 << 24) || (long long)res[0] * res[1] >= (1 << 24))
+    return fail(DRRT_ERR_ARG, "grid extents too large for 24-bit index arithmetic");
   V->data = rif; V->W = res[0]; V->H = res[1]; V->D = res[2];
   V->sy = res[0]; V->sz = res[0] * res[1];
   V->inv_h = 1.0f / h; V->inv_h2 = V->inv_h * V->inv_h;
