@@ -20,6 +20,7 @@ FLAG_CORRECTED_H = 2
 FLAG_NO_ZERO = 4
 FLAG_DIRECT_ATOMICS = 8
 FLAG_DEBUG_COUNTERS = 16
+FLAG_LDS_BRICKS = 32
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
 

@@ -204,12 +204,14 @@ DRRT_HD void fwd_init(const Vol& V, FwdState& s) {
   s.esc = false;                                                                      // :62
 }
 
+// `have` = the ray is inside (its gathers are unmasked); then (c, t) are its cell and the 8 taps of
+// the refractive-index grid there -- fetched by the caller from global memory or from an LDS brick.
 template <int MODE>
-DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s) {
+DRRT_HD void fwd_step_taps(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s,
+                           bool have, const Cell& c, const Taps& t) {
   float n = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-  if (s.inside) {                                                           // masked gather (Q4)
-    Cell c = locate(V, s.x, s.y, s.z);
-    Sample q = interp<false>(fetch(V.data, c), c.wx, c.wy, c.wz);
+  if (have) {                                                               // masked gather (Q4)
+    Sample q = interp<false>(t, c.wx, c.wy, c.wz);
     n = q.n; gx = q.gx * V.inv_h; gy = q.gy * V.inv_h; gz = q.gz * V.inv_h;
   }
   const float dsn = ds * n;
@@ -219,8 +221,8 @@ DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, Fwd
   if (MODE == 2) {                                                          // :287-288
     float d = 0.f;
     if (s.inside) {
-      Cell c = locate(V, s.x, s.y, s.z);
-      d = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n;
+      Cell c2 = locate(V, s.x, s.y, s.z);
+      d = interp<false>(fetch(sdf, c2), c2.wx, c2.wy, c2.wz).n;
     }
     cur_inside = d < 0.f;
   } else {
@@ -240,6 +242,18 @@ DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, Fwd
     s.xtx = s.x; s.xty = s.y; s.xtz = s.z; s.vtx = s.vx; s.vty = s.vy; s.vtz = s.vz;
   }
   s.inside = cur_inside;                                                    // :86
+}
+
+template <int MODE>
+DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s) {
+  Cell c; Taps t;
+  c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0; c.wx = c.wy = c.wz = 0.f;
+  t.v000 = t.v100 = t.v010 = t.v110 = t.v001 = t.v101 = t.v011 = t.v111 = 0.f;
+  if (s.inside) {
+    c = locate(V, s.x, s.y, s.z);
+    t = fetch(V.data, c);
+  }
+  fwd_step_taps<MODE>(V, sdf, ds, s, s.inside, c, t);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -31,6 +31,7 @@ class Options:
     corrected_h: bool = False     # adjoint: divide gradient splat by h; default = as written
     check_failed: bool = True     # sync + print "failed to exit all rays" like src/tracer.cpp:89-90
     direct_atomics: bool = False  # adjoint: one global atomic per tap (debug / A-B)
+    lds_bricks: bool = False      # forward: opt-in LDS-staged bricks of the grid (bit-identical; slower on MI355X)
 
 
 options = Options()
@@ -55,6 +56,8 @@ def _flags(adjoint: bool = False) -> int:
         f |= _lib.FLAG_CORRECTED_H
     if adjoint and options.direct_atomics:
         f |= _lib.FLAG_DIRECT_ATOMICS
+    if not adjoint and options.lds_bricks:
+        f |= _lib.FLAG_LDS_BRICKS
     return f
 
 

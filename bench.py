@@ -117,12 +117,15 @@ def main():
     ap.add_argument("--rays", type=int, default=1024 * 1024, help="rays per GPU (perfect square)")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--direct-atomics", action="store_true")
+    ap.add_argument("--lds-bricks", action="store_true", help="forward: opt-in LDS-staged grid bricks")
     ap.add_argument("--no-order-reuse", action="store_true",
                     help="adjoint computes its own visit order instead of reusing the forward's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-counters", action="store_true", help="print LDS-window counters (stderr)")
     ap.add_argument("--experiment", type=int, default=0, help="development ablation id (0 = product)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
+                                                        "to rehearse the multi-rank flow on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,11 +133,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but only {ndev} GPUs visible")
+    local = local % ndev                         # gloo rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29544")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     from adjointnonlinearraytracing_amd import _lib
     lib = _lib.load()            # loud failure if the HIP library is missing
@@ -145,6 +158,7 @@ def main():
     nvox = rif.numel()
     res = (C.c_int * 3)(R, R, R)
     flags = 0 if args.no_sort else _lib.FLAG_SORT_RAYS
+    fflags = flags | (_lib.FLAG_LDS_BRICKS if args.lds_bricks else 0)
     aflags = flags | (_lib.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0)
     aflags |= (_lib.FLAG_DEBUG_COUNTERS if args.debug_counters else 0) | ((args.experiment & 0xff) << 8)
     ws = torch.empty(int(lib.drrt_workspace_bytes(n, flags)) + 1024, dtype=torch.uint8, device=dev)
@@ -158,7 +172,7 @@ def main():
 
     def step():
         _lib.check(lib.drrt_trace_f32(p(rif), nvox, res, n, p(pos), p(vel), h, ds, p(xt), p(vt),
-                                      p(st_f), p(ws), ws.numel(), flags, stream))
+                                      p(st_f), p(ws), ws.numel(), fflags, stream))
         if flags and not args.no_order_reuse:        # adjoint visits rays in the forward's bundle order
             lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
         _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),

@@ -60,6 +60,10 @@ extern "C" {
 #define DRRT_FLAG_DIRECT_ATOMICS 8u /* adjoint only: bypass the LDS gradient windows and issue
                                        one global atomic per tap (debug / A-B measurement)        */
 
+#define DRRT_FLAG_LDS_BRICKS   32u  /* forward only (opt-in): stage per-wave bricks of the grid in LDS and
+                                       read the taps from there instead of gathering from global
+                                       memory every step.  Bit-identical results; measured slower than
+                                       the default L1-served pair gathers on MI355X   */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
                                        written to the last 512 bytes of the workspace:
                                        [0] LDS-window flushes, [1] ray-steps accumulated through

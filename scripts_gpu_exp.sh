@@ -2,7 +2,7 @@
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; echo "pytest_rc=$?" >> gpurun_out/pytest_gpu.log
 tail -3 gpurun_out/pytest_gpu.log
-for args in "" "--experiment 1"; do
+for args in "" "--no-lds-bricks"; do
   echo "== bench $args"
   timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline $args 2> gpurun_out/exp.err | python -c "
 import json,sys

@@ -100,6 +100,36 @@ def test_backtrace_matches_oracle(gpu, oracle, drrt_mod, kind, R, n, sort, corre
         assert abs(float(g.sum())) <= 1e-3 * float(g.abs().sum() + 1e-30)
 
 
+@pytest.mark.parametrize("sort", [True, False])
+def test_lds_bricks_are_bit_identical_to_global_gathers(gpu, drrt_mod, sort):
+    """Forward march with per-wave LDS bricks of the grid (opt-in, DRRT_FLAG_LDS_BRICKS) vs the default
+    global pair gathers: the taps are the same floats, so exit rays, plane masks and step
+    counts must be identical.  Unsorted six-view rays exercise the out-of-brick fallback; the
+    tiny 5^3 grid exercises bricks larger than the volume."""
+    for R, n in ((65, 4000), (5, 500)):
+        span = 1.0
+        h = span / (R - 1); ds = h / 2
+        rif = _t(cases.smooth_field(R, seed=4), gpu)
+        pos, vel = cases.cube_rays(n, span, ds, seed=13, tilt=0.3)
+        po = np.tile(np.array([[0.5, 0.7, 0.5]], np.float32) * span, (len(pos), 1))
+        pd = np.tile(np.array([[0, 1, 0]], np.float32), (len(pos), 1))
+        T = drrt_mod.TracerC()
+        drrt_mod.options.sort_rays = sort
+        out = {}
+        for bricks in (True, False):
+            drrt_mod.options.lds_bricks = bricks
+            try:
+                xt, vt = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+                st = drrt_mod.read_stats()
+                xp, vp, fm = T.trace_pln(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), _t(po, gpu), _t(pd, gpu), h, ds)
+            finally:
+                drrt_mod.options.lds_bricks = False
+            out[bricks] = (xt.cpu(), vt.cpu(), st, xp.cpu(), vp.cpu(), fm.cpu())
+        a, b = out[True], out[False]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+        assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+
+
 @pytest.mark.parametrize("kind", ["luneburg", "smooth"])
 def test_window_kernel_equals_direct_atomics(gpu, drrt_mod, kind):
     """The LDS gradient-window kernel (default) and the one-atomic-per-tap kernel
