@@ -42,6 +42,8 @@ SIGNATURES = {
     "drrt_last_error": (C.c_char_p, []),
     "drrt_version": (C.c_char_p, []),
     "drrt_trace_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),
+    "drrt_trace_f16io": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),
+    "drrt_backtrace_f16io": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
     "drrt_trace_pln_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp] + _tail),
     "drrt_trace_target_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp] + _tail),
     "drrt_trace_sdf_f32": (_i, [_vp, _vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),

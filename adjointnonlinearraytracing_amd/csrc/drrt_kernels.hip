@@ -23,6 +23,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <hip/hip_fp16.h>
+
 #include "../../include/drrt_hip.h"
 #include "drrt_device.h"
 
@@ -51,9 +53,25 @@ __device__ __forceinline__ void block_stats(drrt_stats* stats, unsigned steps, u
 }
 
 struct Ray3 { float x, y, z; };
-__device__ __forceinline__ Ray3 ld3(const float* p, size_t i) { return Ray3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
-__device__ __forceinline__ void st3(float* p, size_t i, float a, float b, float c) {
-  p[3 * i] = a; p[3 * i + 1] = b; p[3 * i + 2] = c;
+// Ray arrays are (n,3) row-major, fp32 or -- for the *_f16io entry points ("fp16 ray state", config 5
+// of BASELINE.json) -- IEEE half.  Half values are widened exactly on load; the march, the adjoint
+// recurrences and the gradient accumulation are always fp32; outputs are rounded to half once.
+__device__ __forceinline__ Ray3 ld3(const void* p, size_t i, int half = 0) {
+  if (half) {
+    const __half* q = (const __half*)p;
+    return Ray3{__half2float(q[3 * i]), __half2float(q[3 * i + 1]), __half2float(q[3 * i + 2])};
+  }
+  const float* q = (const float*)p;
+  return Ray3{q[3 * i], q[3 * i + 1], q[3 * i + 2]};
+}
+__device__ __forceinline__ void st3(void* p, size_t i, float a, float b, float c, int half = 0) {
+  if (half) {
+    __half* q = (__half*)p;
+    q[3 * i] = __float2half_rn(a); q[3 * i + 1] = __float2half_rn(b); q[3 * i + 2] = __float2half_rn(c);
+  } else {
+    float* q = (float*)p;
+    q[3 * i] = a; q[3 * i + 1] = b; q[3 * i + 2] = c;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -62,9 +80,10 @@ __device__ __forceinline__ void st3(float* p, size_t i, float a, float b, float 
 struct TraceArgs {
   Vol vol;
   const float* sdf;            // MODE 2
-  const float* pos; const float* vel;
+  const void* pos; const void* vel;         // fp32, or half when io_half
   const float* pln_o; const float* pln_d;   // MODE 1
-  float* xt; float* vt; uint8_t* failmask;
+  void* xt; void* vt; uint8_t* failmask;
+  int io_half;
   const uint32_t* perm;        // nullable: visit order
   drrt_stats* stats;
   size_t n;
@@ -78,7 +97,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
   unsigned steps = 0, failed = 0;
   if (t < a.n) {
     const size_t i = a.perm ? (size_t)a.perm[t] : t;
-    Ray3 p = ld3(a.pos, i), u = ld3(a.vel, i);
+    Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
     const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
     float po[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
     if (MODE == 1) {
@@ -87,8 +106,8 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
     }
     RayOut r = trace_ray<MODE>(a.vol, a.sdf, a.ds, a.max_steps, pp, vv, po, pd);
     steps = r.steps; failed = r.act ? 1u : 0u;
-    st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2]);
-    st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2]);
+    st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2], a.io_half);
+    st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2], a.io_half);
     if (MODE == 1) a.failmask[i] = r.esc ? 0 : 1;                           // src/tracer.cpp:171
   }
   block_stats(a.stats, steps, failed);
@@ -163,7 +182,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
   bool live = t < a.n;
   if (live) {
     i = a.perm ? (size_t)a.perm[t] : t;
-    Ray3 p = ld3(a.pos, i), u = ld3(a.vel, i);
+    Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
     s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
     if (MODE == 1) {
       Ray3 o = ld3(a.pln_o, i), d = ld3(a.pln_d, i);
@@ -220,8 +239,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
   if (t < a.n) {
     if (!s.esc) { s.xtx = s.x; s.xty = s.y; s.xtz = s.z; }                  // :95 (vt stays, Q6)
     failed = s.esc ? 0u : 1u;
-    st3(a.xt, i, s.xtx, s.xty, s.xtz);
-    st3(a.vt, i, s.vtx, s.vty, s.vtz);
+    st3(a.xt, i, s.xtx, s.xty, s.xtz, a.io_half);
+    st3(a.vt, i, s.vtx, s.vty, s.vtz, a.io_half);
     if (MODE == 1) a.failmask[i] = s.esc ? 0 : 1;                           // src/tracer.cpp:171
   }
   block_stats(a.stats, steps, failed);
@@ -286,7 +305,8 @@ __global__ void __launch_bounds__(kBlock) k_target_b(TargetArgs a) {
 struct BackArgs {
   Vol vol;
   const float* sdf;
-  const float* xt; const float* vt; const float* dx; const float* dv;
+  const void* xt; const void* vt; const void* dx; const void* dv;   // fp32, or half when io_half
+  int io_half;
   float* grad;
   const uint32_t* perm;
   drrt_stats* stats;
@@ -304,7 +324,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
   unsigned steps = 0;
   if (t < a.n) {
     const size_t i = a.perm ? (size_t)a.perm[t] : t;
-    Ray3 p = ld3(a.xt, i), u = ld3(a.vt, i), gxv = ld3(a.dx, i), gvv = ld3(a.dv, i);
+    Ray3 p = ld3(a.xt, i, a.io_half), u = ld3(a.vt, i, a.io_half), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
     const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
     const float dxx[3] = {gxv.x, gxv.y, gxv.z}, dvv[3] = {gvv.x, gvv.y, gvv.z};
     float* grad = a.grad;
@@ -349,8 +369,11 @@ typedef double win_t;
 #ifndef DRRT_WIN
 #define DRRT_WIN 10
 #endif
+#ifndef DRRT_WIN_PAD
+#define DRRT_WIN_PAD 1
+#endif
 constexpr int kWinX = DRRT_WIN, kWinY = DRRT_WIN, kWinZ = DRRT_WIN;
-constexpr int kWinPX = DRRT_WIN + 1;                      // padded row pitch
+constexpr int kWinPX = DRRT_WIN + DRRT_WIN_PAD;           // row pitch
 constexpr int kWinSY = kWinPX, kWinSZ = kWinPX * kWinY;   // LDS strides of y and z
 constexpr int kWinFloats = kWinSZ * kWinZ;                // 1100 slots = 8.6 KiB per wave
 constexpr int kWavesPerBlock = kBlock / kWave;
@@ -482,7 +505,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
   s.active = false;
   if (t < a.n) {
     const size_t i = a.perm ? (size_t)a.perm[t] : t;
-    Ray3 p = ld3(a.xt, i), u = ld3(a.vt, i), gxv = ld3(a.dx, i), gvv = ld3(a.dv, i);
+    Ray3 p = ld3(a.xt, i, a.io_half), u = ld3(a.vt, i, a.io_half), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
     s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
     adj_init(V, a.ds, gxv.x, gxv.y, gxv.z, gvv.x, gvv.y, gvv.z, s);
     if (MODE == 1 && s.active) {                                            // src/tracer.cpp:476-477
@@ -688,7 +711,7 @@ using namespace drrt;
 // from drrt_sort.hip
 namespace drrt {
 size_t sort_workspace_bytes(size_t n);
-hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const float* pos, const float* vel,
+hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void* pos, const void* vel, int io_half,
                                     float dir_sign, void* ws, size_t ws_bytes, const uint32_t** perm_out,
                                     hipStream_t stream);
 }
@@ -807,8 +830,9 @@ static int zero_stats(drrt_stats* stats, hipStream_t s) {
   return e == hipSuccess ? DRRT_OK : fail_hip(e, "hipMemsetAsync(stats)");
 }
 
-static int maybe_sort(const Vol& V, float h, size_t n, const float* pos, const float* vel, float dir_sign,
-                      unsigned flags, void* ws, size_t ws_bytes, const uint32_t** perm, hipStream_t s) {
+static int maybe_sort(const Vol& V, float h, size_t n, const void* pos, const void* vel, float dir_sign,
+                      unsigned flags, void* ws, size_t ws_bytes, const uint32_t** perm, hipStream_t s,
+                      int io_half = 0) {
   *perm = nullptr;
   // a hint from the caller (normally the paired forward call's order) replaces the sort; it is
   // consumed by this call whether or not it is usable
@@ -818,7 +842,7 @@ static int maybe_sort(const Vol& V, float h, size_t n, const float* pos, const f
   if (!(flags & DRRT_FLAG_SORT_RAYS) || n < 2) return DRRT_OK;
   if (!ws || ws_bytes < sort_workspace_bytes(n)) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_SORT_RAYS");
   ProfScope prof(DRRT_PROF_SORT, s);
-  hipError_t e = sort_rays_by_entry_voxel(V, h, n, pos, vel, dir_sign, ws, ws_bytes, perm, s);
+  hipError_t e = sort_rays_by_entry_voxel(V, h, n, pos, vel, io_half, dir_sign, ws, ws_bytes, perm, s);
   if (e == hipSuccess) { g_last_order = *perm; g_last_order_n = n; }
   return e == hipSuccess ? DRRT_OK : fail_hip(e, "sort_rays_by_entry_voxel");
 }
@@ -830,9 +854,9 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) /
 
 template <int MODE>
 static int run_trace(const float* rif, const float* sdf, long long nvox, const int res[3], size_t n,
-                     const float* pos, const float* vel, const float* pln_o, const float* pln_d,
-                     float h, float ds, float* xt, float* vt, uint8_t* failmask, drrt_stats* stats,
-                     void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+                     const void* pos, const void* vel, const float* pln_o, const float* pln_d,
+                     float h, float ds, void* xt, void* vt, uint8_t* failmask, drrt_stats* stats,
+                     void* ws, size_t ws_bytes, unsigned flags, void* stream, int io_half = 0) {
   g_err[0] = 0;
   hipStream_t s = (hipStream_t)stream;
   TraceArgs a{};
@@ -843,7 +867,8 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
   if (MODE == 2 && !sdf) return fail(DRRT_ERR_ARG, "null sdf pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
   rc = zero_stats(stats, s); if (rc) return rc;
-  rc = maybe_sort(a.vol, h, n, pos, vel, 1.f, flags, ws, ws_bytes, &a.perm, s); if (rc) return rc;
+  rc = maybe_sort(a.vol, h, n, pos, vel, 1.f, flags, ws, ws_bytes, &a.perm, s, io_half); if (rc) return rc;
+  a.io_half = io_half;
   a.sdf = sdf; a.pos = pos; a.vel = vel; a.pln_o = pln_o; a.pln_d = pln_d;
   a.xt = xt; a.vt = vt; a.failmask = failmask; a.stats = stats; a.n = n; a.ds = ds;
   a.max_steps = (MODE == 2) ? steps_sdf(h, res, ds) : steps_fwd(h, res, ds);
@@ -863,6 +888,13 @@ extern "C" int drrt_trace_f32(const float* rif, long long nvox, const int res[3]
                               drrt_stats* stats, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
   return run_trace<0>(rif, nullptr, nvox, res, n, pos, vel, nullptr, nullptr, h, ds, xt, vt, nullptr,
                       stats, ws, ws_bytes, flags, stream);
+}
+
+extern "C" int drrt_trace_f16io(const float* rif, long long nvox, const int res[3], size_t n,
+                                const void* pos, const void* vel, float h, float ds, void* xt, void* vt,
+                                drrt_stats* stats, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+  return run_trace<0>(rif, nullptr, nvox, res, n, pos, vel, nullptr, nullptr, h, ds, xt, vt, nullptr,
+                      stats, ws, ws_bytes, flags, stream, 1);
 }
 
 extern "C" int drrt_trace_pln_f32(const float* rif, long long nvox, const int res[3], size_t n,
@@ -913,9 +945,9 @@ extern "C" int drrt_trace_target_f32(const float* rif, long long nvox, const int
 
 template <int MODE>
 static int run_backtrace(const float* rif, const float* sdf, long long nvox, const int res[3], size_t n,
-                         const float* xt, const float* vt, const float* dx, const float* dv,
+                         const void* xt, const void* vt, const void* dx, const void* dv,
                          float h, float ds, float* grad, drrt_stats* stats, void* ws, size_t ws_bytes,
-                         unsigned flags, void* stream) {
+                         unsigned flags, void* stream, int io_half = 0) {
   g_err[0] = 0;
   hipStream_t s = (hipStream_t)stream;
   BackArgs a{};
@@ -931,7 +963,8 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   if (n == 0) return DRRT_OK;
   if (!xt || !vt || !dx || !dv) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
-  rc = maybe_sort(a.vol, h, n, xt, vt, -1.f, flags, ws, ws_bytes, &a.perm, s); if (rc) return rc;
+  rc = maybe_sort(a.vol, h, n, xt, vt, -1.f, flags, ws, ws_bytes, &a.perm, s, io_half); if (rc) return rc;
+  a.io_half = io_half;
   a.sdf = sdf; a.xt = xt; a.vt = vt; a.dx = dx; a.dv = dv; a.grad = grad; a.stats = stats;
   a.n = n; a.ds = ds; a.max_steps = steps_adj(h, res, ds);
   a.grad_scale = (flags & DRRT_FLAG_CORRECTED_H) ? a.vol.inv_h : 1.0f;
@@ -959,6 +992,13 @@ extern "C" int drrt_backtrace_f32(const float* rif, long long nvox, const int re
                                   float h, float ds, float* grad, drrt_stats* stats, void* ws,
                                   size_t ws_bytes, unsigned flags, void* stream) {
   return run_backtrace<0>(rif, nullptr, nvox, res, n, xt, vt, dx, dv, h, ds, grad, stats, ws, ws_bytes, flags, stream);
+}
+
+extern "C" int drrt_backtrace_f16io(const float* rif, long long nvox, const int res[3], size_t n,
+                                    const void* xt, const void* vt, const void* dx, const void* dv,
+                                    float h, float ds, float* grad, drrt_stats* stats, void* ws,
+                                    size_t ws_bytes, unsigned flags, void* stream) {
+  return run_backtrace<0>(rif, nullptr, nvox, res, n, xt, vt, dx, dv, h, ds, grad, stats, ws, ws_bytes, flags, stream, 1);
 }
 
 extern "C" int drrt_backtrace_sdf_f32(const float* rif, const float* sdf, long long nvox, const int res[3],

@@ -18,6 +18,7 @@
 // For the adjoint the march direction is -vt and the "start" is the recorded exit sample xt.
 // The permutation only changes the VISIT order; results are written back in the caller's ray order.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
@@ -28,13 +29,18 @@ namespace drrt {
 constexpr int kKeyBitsPerAxis = 10;
 constexpr int kKeyBits = 6 * kKeyBitsPerAxis;
 
-__global__ void __launch_bounds__(256) k_chord_keys(Vol V, size_t n, const float* __restrict__ pos,
-                                                    const float* __restrict__ vel, float dir_sign,
+__device__ __forceinline__ float ldr(const void* p, size_t k, int half) {
+  return half ? __half2float(((const __half*)p)[k]) : ((const float*)p)[k];
+}
+
+__global__ void __launch_bounds__(256) k_chord_keys(Vol V, size_t n, const void* __restrict__ pos,
+                                                    const void* __restrict__ vel, int io_half, float dir_sign,
                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
-  float d[3] = {dir_sign * vel[3 * i], dir_sign * vel[3 * i + 1], dir_sign * vel[3 * i + 2]};
+  float p[3] = {ldr(pos, 3 * i, io_half), ldr(pos, 3 * i + 1, io_half), ldr(pos, 3 * i + 2, io_half)};
+  float d[3] = {dir_sign * ldr(vel, 3 * i, io_half), dir_sign * ldr(vel, 3 * i + 1, io_half),
+                dir_sign * ldr(vel, 3 * i + 2, io_half)};
   const float b[3] = {V.bx, V.by, V.bz};
   float tmin = 0.f, tmax = 3.0e38f;
   bool hit = true;
@@ -89,7 +95,7 @@ size_t sort_workspace_bytes(size_t n) {
   return 2 * al(n * sizeof(uint64_t)) + 2 * al(n * sizeof(uint32_t)) + al(cub_temp_bytes(n));
 }
 
-hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const float* pos, const float* vel,
+hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void* pos, const void* vel, int io_half,
                                     float dir_sign, void* ws, size_t ws_bytes, const uint32_t** perm_out,
                                     hipStream_t stream) {
   (void)h;
@@ -102,7 +108,7 @@ hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const float
   void* temp = base + 2 * k8 + 2 * k4;
   size_t temp_bytes = ws_bytes - (2 * k8 + 2 * k4);
   hipLaunchKernelGGL(k_chord_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, V, n, pos, vel,
-                     dir_sign, keys_in, idx_in);
+                     io_half, dir_sign, keys_in, idx_in);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint64_t*)keys_in, keys_out,

@@ -80,8 +80,13 @@ def _f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
-def _rays(t: torch.Tensor, device: torch.device, n: Optional[int] = None) -> torch.Tensor:
-    t = _f32(t, device)
+def _is_half(*ts: torch.Tensor) -> bool:
+    """fp16 ray-state mode (BASELINE config 5): every ray tensor of the call is float16."""
+    return all(t.dtype == torch.float16 for t in ts)
+
+
+def _rays(t: torch.Tensor, device: torch.device, n: Optional[int] = None, half: bool = False) -> torch.Tensor:
+    t = t.detach().to(device=device, dtype=torch.float16).contiguous() if half else _f32(t, device)
     if t.dim() != 2 or t.shape[1] != 3 or (n is not None and t.shape[0] != n):
         raise RuntimeError(f"expected a ({'N' if n is None else n},3) ray tensor, got {tuple(t.shape)}")
     return t
@@ -145,16 +150,19 @@ class TracerC:
 
     # ---- forward ------------------------------------------------------------------------
     def trace(self, rif, res, pos, vel, h, ds) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Tracer::trace, src/tracer.cpp:35-100."""
+        """Tracer::trace, src/tracer.cpp:35-100.  float16 pos AND vel select the fp16 ray-state
+        variant (drrt_trace_f16io): half in, fp32 march, half out."""
         dev = _dev(rif)
         with torch.cuda.device(dev):
-            rif_, pos_ = _f32(rif, dev).reshape(-1), _rays(pos, dev)
+            half = _is_half(pos, vel)
+            rif_, pos_ = _f32(rif, dev).reshape(-1), _rays(pos, dev, half=half)
             n = pos_.shape[0]
-            vel_ = _rays(vel, dev, n)
+            vel_ = _rays(vel, dev, n, half=half)
             xt, vt = torch.empty_like(pos_), torch.empty_like(vel_)
             fl = _flags()
             ws, st = _workspace(n, fl, dev), _new_stats(dev)
-            _lib.check(_lib.load().drrt_trace_f32(
+            fn = _lib.load().drrt_trace_f16io if half else _lib.load().drrt_trace_f32
+            _lib.check(fn(
                 _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), float(h), float(ds),
                 _p(xt), _p(vt), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
             _capture_order(n, dev)
@@ -237,17 +245,20 @@ class TracerC:
     # ---- adjoint ------------------------------------------------------------------------
     def backtrace(self, rif, res, xt, vt, dx, dv, h, ds, order: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Tracer::backtrace, src/tracer.cpp:384-440 -> flat dL/dn (fp32[nvox]).
-        `order` (optional, not in the reference): visit order of the paired forward call."""
+        `order` (optional, not in the reference): visit order of the paired forward call.
+        float16 xt, vt, dx, dv select the fp16 ray-state variant (fp32 recurrences and accumulation)."""
         dev = _dev(rif)
         with torch.cuda.device(dev):
-            rif_, xt_ = _f32(rif, dev).reshape(-1), _rays(xt, dev)
+            half = _is_half(xt, vt, dx, dv)
+            rif_, xt_ = _f32(rif, dev).reshape(-1), _rays(xt, dev, half=half)
             n = xt_.shape[0]
-            vt_, dx_, dv_ = _rays(vt, dev, n), _rays(dx, dev, n), _rays(dv, dev, n)
+            vt_, dx_, dv_ = _rays(vt, dev, n, half=half), _rays(dx, dev, n, half=half), _rays(dv, dev, n, half=half)
             grad = torch.empty_like(rif_)
             fl = _flags(adjoint=True)
             ws, st = _workspace(n, fl, dev), _new_stats(dev)
             _hint(order, n)
-            _lib.check(_lib.load().drrt_backtrace_f32(
+            fn = _lib.load().drrt_backtrace_f16io if half else _lib.load().drrt_backtrace_f32
+            _lib.check(fn(
                 _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
                 float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
         return grad

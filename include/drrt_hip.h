@@ -108,6 +108,16 @@ DRRT_API int drrt_trace_f32(const float* rif, long long nvox, const int res[3], 
                    drrt_stats* stats, void* workspace, size_t workspace_bytes,
                    unsigned flags, void* stream);
 
+/* fp16 ray-state variant of drrt_trace_f32 (BASELINE.json config 5: "fp16 ray state + fp32 adjoint
+ * accumulate"; the reference is fp32-only, include/types.h:36-46).  pos, vel, xt, vt are (n,3) IEEE
+ * half; values are widened exactly on load, the march is fp32, outputs are rounded to half once:
+ * result == half(drrt_trace_f32(float(pos), float(vel))) bit for bit.                            */
+DRRT_API int drrt_trace_f16io(const float* rif, long long nvox, const int res[3], size_t n,
+                     const void* pos_h, const void* vel_h, float h, float ds,
+                     void* xt_h, void* vt_h,
+                     drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                     unsigned flags, void* stream);
+
 /* Tracer::trace_plane -- src/tracer.cpp:102-172, bound as TracerC.trace_pln (src/drrt.cpp:52).
  * failmask[i] = 1 for rays that never got flagged escaped (uint8, n entries).                 */
 DRRT_API int drrt_trace_pln_f32(const float* rif, long long nvox, const int res[3], size_t n,
@@ -149,6 +159,14 @@ DRRT_API int drrt_backtrace_f32(const float* rif, long long nvox, const int res[
                        float h, float ds, float* grad,
                        drrt_stats* stats, void* workspace, size_t workspace_bytes,
                        unsigned flags, void* stream);
+
+/* fp16 ray-state variant of drrt_backtrace_f32: xt, vt, dx, dv are (n,3) IEEE half, the adjoint
+ * recurrences and the accumulation into `grad` stay fp32.                                        */
+DRRT_API int drrt_backtrace_f16io(const float* rif, long long nvox, const int res[3], size_t n,
+                         const void* xt_h, const void* vt_h, const void* dx_h, const void* dv_h,
+                         float h, float ds, float* grad,
+                         drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                         unsigned flags, void* stream);
 
 /* Tracer::backtrace_sdf -- src/tracer.cpp:443-509, TracerC.backtrace_sdf (src/drrt.cpp:57).     */
 DRRT_API int drrt_backtrace_sdf_f32(const float* rif, const float* sdf, long long nvox, const int res[3],

@@ -401,3 +401,100 @@ def test_golden_fuel_injection(gpu, oracle, drrt_mod):
     assert np.array_equal(xt.cpu().numpy(), o32["xt"]) and np.array_equal(vt.cpu().numpy(), o32["vt"])
     bad, unexplained = cases.step_flip_report(xt.cpu().numpy(), vt.cpu().numpy(), z["xt"], z["vt"], ds, tol=2e-5)
     assert unexplained <= 0.002 and bad <= 0.05
+
+
+def test_non_cubic_grid(gpu, oracle, drrt_mod):
+    """res = (W,H,D) all different; flat index (z*H + y)*W + x as src/volume.cpp:134-141 writes it."""
+    W, H, D = 20, 14, 9
+    h, ds = 0.25, 0.125
+    rng = np.random.default_rng(5)
+    rif = (1.0 + 0.3 * rng.random(W * H * D)).astype(np.float32)
+    ext = np.array([(W - 1) * h, (H - 1) * h, (D - 1) * h])
+    pos = (rng.random((5000, 3)) * ext * 1.2 - 0.1 * ext).astype(np.float32)
+    vel = rng.normal(size=(5000, 3)); vel = (vel / np.linalg.norm(vel, axis=1, keepdims=True)).astype(np.float32)
+    res = (W, H, D)
+    T = drrt_mod.TracerC()
+    for sort in (True, False):
+        drrt_mod.options.sort_rays = sort
+        xt, vt = T.trace(_t(rif, gpu), res, _t(pos, gpu), _t(vel, gpu), h, ds)
+        with oracle.arith("factored"):
+            o = oracle.trace(rif, res, pos, vel, h, ds, dtype=np.float32)
+        assert np.array_equal(xt.cpu().numpy(), o["xt"]) and np.array_equal(vt.cpu().numpy(), o["vt"])
+        dx = rng.normal(size=pos.shape).astype(np.float32); dv = rng.normal(size=pos.shape).astype(np.float32)
+        g = T.backtrace(_t(rif, gpu), res, xt, vt, _t(dx, gpu), _t(dv, gpu), h, ds)
+        st = drrt_mod.read_stats()
+        with oracle.arith("factored"):
+            ob = oracle.backtrace(rif, res, o["xt"], o["vt"], dx, dv, h, ds, dtype=np.float32)
+        assert st["ray_steps"] == ob["steps_total"] and cases.rel_l2(g.cpu().numpy(), ob["grad"]) <= 2e-5
+
+
+def test_full_size_properties(gpu, drrt_mod):
+    """BASELINE.json's full size (256^3 grid, 1M rays, ~512 steps) through size-independent properties:
+    determinism of the forward march, every ray exits with the expected step count, linearity of the
+    adjoint in (dx, dv), shard-sum == whole, window kernel == direct atomics, sum(dL/dn) == 0 in a
+    uniform medium."""
+    import bench
+    R, n = 256, 1024 * 1024
+    rif, pos, vel, h, ds = bench.make_workload(R, n, gpu, seed=0)
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = True
+    xt, vt = T.trace(rif, rif.shape, pos, vel, h, ds)
+    st = drrt_mod.read_stats()
+    order = drrt_mod.last_order
+    # straight corner rays take 510-511 steps, rays through the ball (|v| = n > 1) fewer
+    assert st["n_failed"] == 0 and 470 * n <= st["ray_steps"] <= 515 * n and 505 <= st["iters"] < 2048
+    xt2, vt2 = T.trace(rif, rif.shape, pos, vel, h, ds)
+    assert torch.equal(xt, xt2) and torch.equal(vt, vt2)                     # deterministic, order-independent
+    drrt_mod.options.sort_rays = False
+    xt3, _ = T.trace(rif, rif.shape, pos, vel, h, ds)
+    drrt_mod.options.sort_rays = True
+    assert torch.equal(xt, xt3)
+    assert float((xt[:, 1] >= 1.0 - 1e-6).float().mean()) > 0.99            # exits through the far face
+    dx1, dv1 = torch.randn_like(xt), torch.randn_like(vt)
+    dx2, dv2 = torch.randn_like(xt), torch.randn_like(vt)
+    g1 = T.backtrace(rif, rif.shape, xt, vt, dx1, dv1, h, ds, order=order)
+    g2 = T.backtrace(rif, rif.shape, xt, vt, dx2, dv2, h, ds, order=order)
+    g12 = T.backtrace(rif, rif.shape, xt, vt, 2 * dx1 - 3 * dx2, 2 * dv1 - 3 * dv2, h, ds, order=order)
+    lin = 2 * g1 - 3 * g2
+    assert float((g12 - lin).norm() / lin.norm()) <= 2e-5                    # linear in the seed
+    half = n // 2
+    ga = T.backtrace(rif, rif.shape, xt[:half], vt[:half], dx1[:half], dv1[:half], h, ds)
+    gb = T.backtrace(rif, rif.shape, xt[half:], vt[half:], dx1[half:], dv1[half:], h, ds)
+    assert float((ga + gb - g1).norm() / g1.norm()) <= 2e-5                  # shard sum == whole (multi-GPU reduction)
+    sub = slice(0, n, 16)
+    drrt_mod.options.direct_atomics = True
+    try:
+        gd = T.backtrace(rif, rif.shape, xt[sub], vt[sub], dx1[sub], dv1[sub], h, ds)
+    finally:
+        drrt_mod.options.direct_atomics = False
+    gw = T.backtrace(rif, rif.shape, xt[sub], vt[sub], dx1[sub], dv1[sub], h, ds)
+    assert float((gw - gd).norm() / gd.norm()) <= 2e-5                       # LDS windows == direct atomics
+    uni = torch.full_like(rif, 1.25)
+    xu, vu = T.trace(uni, uni.shape, pos, vel, h, ds)
+    gu = T.backtrace(uni, uni.shape, xu, vu, dx1, dv1, h, ds)
+    assert abs(float(gu.double().sum())) <= 1e-4 * float(gu.double().abs().sum())
+
+
+def test_fp16_ray_state_mode(gpu, drrt_mod):
+    """BASELINE config 5: fp16 ray state + fp32 adjoint accumulate (no counterpart in the reference,
+    which is fp32-only, include/types.h:36-46).  Half inputs are widened exactly, the march is the
+    fp32 march, outputs are rounded once: trace_f16io == half(trace_f32(float(inputs))) bit for bit;
+    the adjoint from half inputs equals the fp32 adjoint from the same (widened) inputs."""
+    R, span = 65, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = _t(cases.luneburg(R), gpu)
+    pos, vel = cases.cube_rays(3000, span, ds, seed=17, tilt=0.2)
+    pos16, vel16 = _t(pos, gpu).half(), _t(vel, gpu).half()
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = True
+    xt16, vt16 = T.trace(rif, rif.shape, pos16, vel16, h, ds)
+    st16 = drrt_mod.read_stats()
+    assert xt16.dtype == torch.float16 and vt16.dtype == torch.float16
+    xt32, vt32 = T.trace(rif, rif.shape, pos16.float(), vel16.float(), h, ds)
+    st32 = drrt_mod.read_stats()
+    assert torch.equal(xt16, xt32.half()) and torch.equal(vt16, vt32.half()) and st16 == st32
+    dx16, dv16 = torch.randn_like(xt16), torch.randn_like(vt16)
+    g16 = T.backtrace(rif, rif.shape, xt16, vt16, dx16, dv16, h, ds)
+    assert g16.dtype == torch.float32
+    g32 = T.backtrace(rif, rif.shape, xt16.float(), vt16.float(), dx16.float(), dv16.float(), h, ds)
+    assert cases.rel_l2(g16.cpu().numpy(), g32.cpu().numpy()) <= 2e-5

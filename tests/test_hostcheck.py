@@ -9,6 +9,7 @@ import pytest
 
 import cases
 import hostcheck_lib as H
+H_ = H
 
 
 @pytest.fixture(scope="module")
@@ -99,3 +100,27 @@ def test_cable_bitwise(oracle):
     kb = H.backtrace_cable(prof, radius, length, k["xt"], k["vt"], dx, dv, ds)
     assert ob["steps_total"] == kb["steps_total"]
     assert np.array_equal(ob["grad"], kb["grad"])       # same ray-major summation order: bitwise
+
+
+def test_non_cubic_grid_bitwise(oracle):
+    """res = (W,H,D) with W != H != D: flat index (z*H + y)*W + x with (W,H,D) = res exactly as
+    src/volume.cpp:110-112,134-141 writes it (the reference's scripts only use cubes, Q2)."""
+    W, H, D = 12, 9, 7
+    h, ds = 0.25, 0.125
+    rng = np.random.default_rng(5)
+    rif = (1.0 + 0.3 * rng.random(W * H * D)).astype(np.float32)
+    ext = np.array([(W - 1) * h, (H - 1) * h, (D - 1) * h])
+    pos = (rng.random((600, 3)) * ext * 1.2 - 0.1 * ext).astype(np.float32)
+    vel = rng.normal(size=(600, 3)); vel = (vel / np.linalg.norm(vel, axis=1, keepdims=True)).astype(np.float32)
+    res = (W, H, D)
+    with oracle.arith("factored"):
+        o = oracle.trace(rif, res, pos, vel, h, ds, dtype=np.float32)
+    k = H_.trace(rif, res, pos, vel, h, ds)
+    assert np.array_equal(o["xt"], k["xt"]) and np.array_equal(o["vt"], k["vt"]) and np.array_equal(o["steps"], k["steps"])
+    dx = rng.normal(size=pos.shape).astype(np.float32); dv = rng.normal(size=pos.shape).astype(np.float32)
+    with oracle.arith("factored"):
+        ob = oracle.backtrace(rif, res, k["xt"], k["vt"], dx, dv, h, ds, dtype=np.float32)
+    kb = H_.backtrace(rif, res, k["xt"], k["vt"], dx, dv, h, ds)
+    assert ob["steps_total"] == kb["steps_total"] and cases.rel_l2(kb["grad"], ob["grad"]) < 2e-6
+    lit = oracle.trace(rif, res, pos, vel, h, ds, dtype=np.float64)
+    assert np.mean(np.linalg.norm(k["xt"] - lit["xt"], axis=1) <= 2e-5) >= 0.98
