@@ -727,6 +727,8 @@ static int fail_hip(hipError_t e, const char* where) {
   return DRRT_ERR_HIP;
 }
 
+namespace drrt { int sensor_fail(int code, const char* msg) { return fail(code, msg); } }   // used by drrt_sensor.hip
+
 extern "C" const char* drrt_last_error(void) { return g_err; }
 
 // ---- visit-order hand-over between paired calls (per host thread) ----------------------------

@@ -1,0 +1,177 @@
+// drrt_sensor.hip -- sensor image splat and its backward ("next" row 1):
+// the step that follows the march in the reference's image experiments.
+//
+// Reference semantics (all torch, /root/reference/core):
+//   sensor.py:195-202  trace_rays_to_plane   t = n.(p - x) / n.v ;  x' = x + t v
+//   sensor.py:5-28     generate_sensor       2-D coords of x' in the sensor frame (t1 = n x t2, t2),
+//                                            foreshortening fs = |v.n|, Grid.Splat(xn, fs*e, average=False)
+//   grid.py:37-64      Grid.index_values     u = xn/h - 0.5, 4x4 taps around floor(u), r = |u - idx|
+//   grid.py:77-81      rbf_tent              w = max(sqrt(2) - r, 0)
+//   grid.py:133-151    Grid.Splat            image[idx] += w/sum(w) * f  for taps inside the image
+//                                            (normalised over ALL 16 taps, in or out)
+// The reference builds ~20 (N,16)-sized temporaries per call and scatters with
+// index_put_(accumulate=True); its backward is torch.autograd through all of that.  Here both
+// directions are one fused kernel each: ray -> plane -> frame -> 16 taps -> fp32 atomics, and the
+// analytic backward (gather 16 taps of dL/dimage, chain through the tent weights, the frame and the
+// plane intersection) producing (grad_x, grad_v) directly -- the seed of Tracer::backtrace.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/drrt_hip.h"
+
+namespace drrt {
+
+struct SensorArgs {
+  const float* x; const float* v; const float* e;   // e nullable -> e_scalar
+  float e_scalar;
+  float p[3], n[3], t1[3], t2[3];
+  int res; float span, inv_hs, half_span;
+  float* image;                // forward out (res*res)
+  const float* grad_image;     // backward in
+  float* grad_x; float* grad_v;
+  size_t n_rays;
+};
+
+struct SensorRay {
+  float den, t, F, u[2];
+  int i1[2];
+  bool ok;
+};
+
+__device__ __forceinline__ SensorRay sensor_locate(const SensorArgs& a, size_t i, float x[3], float v[3]) {
+  SensorRay r;
+  x[0] = a.x[3 * i]; x[1] = a.x[3 * i + 1]; x[2] = a.x[3 * i + 2];
+  v[0] = a.v[3 * i]; v[1] = a.v[3 * i + 1]; v[2] = a.v[3 * i + 2];
+  r.den = v[0] * a.n[0] + v[1] * a.n[1] + v[2] * a.n[2];
+  const float num = (a.p[0] - x[0]) * a.n[0] + (a.p[1] - x[1]) * a.n[1] + (a.p[2] - x[2]) * a.n[2];
+  r.t = num / r.den;                                                  // sensor.py:199-200
+  const float q0 = x[0] + r.t * v[0] - a.p[0], q1 = x[1] + r.t * v[1] - a.p[1], q2 = x[2] + r.t * v[2] - a.p[2];
+  const float xa = q0 * a.t1[0] + q1 * a.t1[1] + q2 * a.t1[2] + a.half_span;    // sensor.py:22-23
+  const float xb = q0 * a.t2[0] + q1 * a.t2[1] + q2 * a.t2[2] + a.half_span;
+  r.u[0] = xa * a.inv_hs - 0.5f; r.u[1] = xb * a.inv_hs - 0.5f;       // grid.py:38
+  const float f0 = floorf(r.u[0]), f1 = floorf(r.u[1]);
+  // rays that miss the image by more than the tap footprint (or are NaN) contribute nothing
+  r.ok = (f0 >= -3.f) & (f0 <= (float)(a.res + 1)) & (f1 >= -3.f) & (f1 <= (float)(a.res + 1));
+  r.i1[0] = r.ok ? (int)f0 : 0; r.i1[1] = r.ok ? (int)f1 : 0;
+  r.F = fabsf(r.den) * (a.e ? a.e[i] : a.e_scalar);                   // sensor.py:18-19
+  return r;
+}
+
+__global__ void __launch_bounds__(256) k_sensor_splat(SensorArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_rays) return;
+  float x[3], v[3];
+  const SensorRay r = sensor_locate(a, i, x, v);
+  if (!r.ok) return;
+  float w[16], wsum = 0.f;
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja) {
+    const float da = r.u[0] - (float)(r.i1[0] - 1 + ja);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const float db = r.u[1] - (float)(r.i1[1] - 1 + jb);
+      const float ww = fmaxf(1.41421356237f - sqrtf(da * da + db * db), 0.f);   // grid.py:79
+      w[ja * 4 + jb] = ww; wsum += ww;
+    }
+  }
+  const float scale = r.F / wsum;                                     // grid.py:145 (all 16 taps)
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja) {
+    const int ia = r.i1[0] - 1 + ja;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const int ib = r.i1[1] - 1 + jb;
+      const float c = w[ja * 4 + jb] * scale;
+      if (((unsigned)ia < (unsigned)a.res) & ((unsigned)ib < (unsigned)a.res) & (c != 0.f))   // grid.py:140
+        unsafeAtomicAdd(a.image + (size_t)ia * a.res + ib, c);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_sensor_splat_bwd(SensorArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_rays) return;
+  float x[3], v[3];
+  const SensorRay r = sensor_locate(a, i, x, v);
+  float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f};
+  if (r.ok) {
+    float W = 0.f, gw = 0.f, gda = 0.f, gdb = 0.f, sda = 0.f, sdb = 0.f;
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja) {
+      const int ia = r.i1[0] - 1 + ja;
+      const float da = r.u[0] - (float)ia;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        const int ib = r.i1[1] - 1 + jb;
+        const float db = r.u[1] - (float)ib;
+        const float rr = sqrtf(da * da + db * db);
+        const float ww = fmaxf(1.41421356237f - rr, 0.f);
+        const bool valid = ((unsigned)ia < (unsigned)a.res) & ((unsigned)ib < (unsigned)a.res);
+        const float g = valid ? a.grad_image[(size_t)ia * a.res + ib] : 0.f;
+        const bool live = (ww > 0.f) & (rr > 0.f);
+        const float inv_r = live ? 1.f / rr : 0.f;
+        const float dwa = -da * inv_r, dwb = -db * inv_r;             // d w / d u
+        W += ww; gw += g * ww; gda += g * dwa; gdb += g * dwb; sda += dwa; sdb += dwb;
+      }
+    }
+    const float G = gw / W;
+    const float k = r.F / W * a.inv_hs;
+    const float ga = k * (gda - G * sda), gb = k * (gdb - G * sdb);    // dL/d xn
+    const float gp0 = ga * a.t1[0] + gb * a.t2[0], gp1 = ga * a.t1[1] + gb * a.t2[1], gp2 = ga * a.t1[2] + gb * a.t2[2];
+    const float vg = (v[0] * gp0 + v[1] * gp1 + v[2] * gp2) / r.den;
+    gx[0] = gp0 - a.n[0] * vg; gx[1] = gp1 - a.n[1] * vg; gx[2] = gp2 - a.n[2] * vg;     // (I - v n^T/den)^T
+    const float ef = G * (a.e ? a.e[i] : a.e_scalar) * (r.den > 0.f ? 1.f : (r.den < 0.f ? -1.f : 0.f));
+    gv[0] = r.t * gx[0] + ef * a.n[0]; gv[1] = r.t * gx[1] + ef * a.n[1]; gv[2] = r.t * gx[2] + ef * a.n[2];
+  }
+  a.grad_x[3 * i] = gx[0]; a.grad_x[3 * i + 1] = gx[1]; a.grad_x[3 * i + 2] = gx[2];
+  a.grad_v[3 * i] = gv[0]; a.grad_v[3 * i + 1] = gv[1]; a.grad_v[3 * i + 2] = gv[2];
+}
+
+int sensor_fail(int code, const char* msg);   // drrt_kernels.hip
+
+static int fill_args(SensorArgs& a, size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                     const float p[3], const float nrm[3], const float t1[3], const float t2[3], int res, float span) {
+  if (!x || !v || !p || !nrm || !t1 || !t2) return sensor_fail(DRRT_ERR_ARG, "null pointer");
+  if (res < 1 || res > 32768 || !(span > 0.f)) return sensor_fail(DRRT_ERR_ARG, "bad sensor resolution / span");
+  a.x = x; a.v = v; a.e = e; a.e_scalar = e_scalar; a.n_rays = n;
+  for (int k = 0; k < 3; ++k) { a.p[k] = p[k]; a.n[k] = nrm[k]; a.t1[k] = t1[k]; a.t2[k] = t2[k]; }
+  a.res = res; a.span = span; a.inv_hs = 1.0f / (span / (float)res); a.half_span = span / 2;
+  return DRRT_OK;
+}
+
+}  // namespace drrt
+
+using namespace drrt;
+
+extern "C" int drrt_sensor_splat_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                                     const float plane_p[3], const float plane_n[3], const float t1[3],
+                                     const float t2[3], int res, float span, float* image, unsigned flags,
+                                     void* stream) {
+  SensorArgs a{};
+  int rc = fill_args(a, n, x, v, e, e_scalar, plane_p, plane_n, t1, t2, res, span); if (rc) return rc;
+  if (!image) return sensor_fail(DRRT_ERR_ARG, "null image pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (!(flags & DRRT_FLAG_NO_ZERO)) {
+    hipError_t e_ = hipMemsetAsync(image, 0, (size_t)res * res * sizeof(float), s);
+    if (e_ != hipSuccess) return sensor_fail(DRRT_ERR_HIP, hipGetErrorString(e_));
+  }
+  if (n == 0) return DRRT_OK;
+  a.image = image;
+  hipLaunchKernelGGL(k_sensor_splat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+
+extern "C" int drrt_sensor_splat_bwd_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                                         const float plane_p[3], const float plane_n[3], const float t1[3],
+                                         const float t2[3], int res, float span, const float* grad_image,
+                                         float* grad_x, float* grad_v, void* stream) {
+  SensorArgs a{};
+  int rc = fill_args(a, n, x, v, e, e_scalar, plane_p, plane_n, t1, t2, res, span); if (rc) return rc;
+  if (!grad_image || !grad_x || !grad_v) return sensor_fail(DRRT_ERR_ARG, "null gradient pointer");
+  if (n == 0) return DRRT_OK;
+  a.grad_image = grad_image; a.grad_x = grad_x; a.grad_v = grad_v;
+  hipLaunchKernelGGL(k_sensor_splat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}

@@ -1,0 +1,97 @@
+"""Counterpart of the part of the reference's ``core/sensor.py`` that directly follows the march:
+``trace_rays_to_plane`` (``:195-202``), ``get_tan_vecs`` (``:219-231``) and ``generate_sensor``
+(``:5-28``), the differentiable 2-D image splat used by the image / Luneburg experiments
+(``core/image_opt.py:99-101``, ``core/luneburg_opt.py:121-123``).
+
+``generate_sensor`` keeps the reference's signature; on ``cuda`` (ROCm) tensors it runs the fused
+HIP kernels (``csrc/drrt_sensor.hip``: ray -> plane -> sensor frame -> 16 tent taps -> atomics, and
+the analytic backward that yields ``(grad_x, grad_v)`` directly) instead of ~20 (N,16)-sized torch
+temporaries + ``index_put_``.  There is no CPU compute path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def trace_rays_to_plane(rays, plane):
+    """core/sensor.py:195-202 (plain torch, unchanged semantics)."""
+    x, v = rays
+    p, n = plane
+    t = torch.matmul(n[:, None, :], (p - x)[:, :, None]).squeeze(2)
+    t = t / torch.matmul(n[:, None, :], v[:, :, None]).squeeze(2)
+    return (x + t * v), v
+
+
+def get_tan_vecs(n, t=None):
+    """core/sensor.py:219-231."""
+    if t is None:
+        t2 = torch.zeros_like(n)
+        if torch.abs(n)[0, -1] > 0.001:
+            t2[0, 0] = 1
+        else:
+            t2[0, -1] = 1
+    else:
+        t2 = t
+    t1 = torch.cross(n, t2, dim=1)
+    return t1, t2
+
+
+def _vec3(t: torch.Tensor):
+    v = t.detach().reshape(-1)[:3].to(torch.float32).cpu().tolist()
+    return (C.c_float * 3)(*v)
+
+
+class _SensorSplat(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, v, e, p, n, t1, t2, res, span):
+        if not x.is_cuda:
+            raise RuntimeError("generate_sensor expects tensors on the cuda (ROCm) device (no CPU path)")
+        dev = x.device
+        with torch.cuda.device(dev):
+            x_ = x.detach().to(torch.float32).contiguous()
+            v_ = v.detach().to(torch.float32).contiguous()
+            nr = x_.shape[0]
+            if isinstance(e, torch.Tensor) and e.numel() > 1:
+                e_ = e.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+                if e_.numel() != nr:
+                    raise RuntimeError("e must be a scalar or have one entry per ray")
+                e_s = 0.0
+            else:
+                e_, e_s = None, float(e)
+            img = torch.empty(int(res), int(res), dtype=torch.float32, device=dev)
+            frame = (_vec3(p), _vec3(n), _vec3(t1), _vec3(t2))
+            _lib.check(_lib.load().drrt_sensor_splat_f32(
+                nr, C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()),
+                C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s, *frame, int(res), float(span),
+                C.c_void_p(img.data_ptr()), 0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.saved = (x_, v_, e_, e_s, frame, int(res), float(span))
+        return img
+
+    @staticmethod
+    def backward(ctx, grad_img):
+        x_, v_, e_, e_s, frame, res, span = ctx.saved
+        dev = x_.device
+        with torch.cuda.device(dev):
+            g = grad_img.detach().to(torch.float32).contiguous()
+            gx, gv = torch.empty_like(x_), torch.empty_like(v_)
+            _lib.check(_lib.load().drrt_sensor_splat_bwd_f32(
+                x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()),
+                C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s, *frame, res, span,
+                C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()), C.c_void_p(gv.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return gx, gv, None, None, None, None, None, None, None
+
+
+def generate_sensor(rays, e, plane, res, span, tangent=None):
+    """core/sensor.py:5-28: image (res, res) of the rays splatted onto the sensor plane
+    (p, n given as (1,3) tensors, one plane per call as in the reference); differentiable w.r.t.
+    the rays."""
+    x, v = rays
+    p, n = plane
+    t1, t2 = get_tan_vecs(n, tangent)
+    return _SensorSplat.apply(x, v, e, p, n, t1, t2, res, span)

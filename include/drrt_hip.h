@@ -183,6 +183,24 @@ DRRT_API int drrt_backtrace_cable_f32(const float* rif, size_t rres, float radiu
                              drrt_stats* stats, void* workspace, size_t workspace_bytes,
                              unsigned flags, void* stream);
 
+/* ---- sensor image splat (SURVEY.md 8.8 "next" row 1; the reference does this in torch) ----------
+ * Forward: core/sensor.py:5-28 generate_sensor = trace_rays_to_plane (:195-202) + sensor frame
+ * (t1 = n x t2, t2; get_tan_vecs :219-231 is evaluated by the caller) + foreshortening |v.n| +
+ * Grid.Splat(average=False) with 4x4 tent taps (core/grid.py:37-64,77-81,133-151).
+ *   x, v      (n,3) fp32 rays (normally the exit rays of drrt_trace_f32)
+ *   e         per-ray energy fp32[n], or NULL to use e_scalar for every ray
+ *   plane_p/n, t1, t2   HOST pointers to 3 floats each (one sensor plane per call, as in the reference)
+ *   image     fp32[res*res], row-major image[ia*res + ib] with ia along t1; zeroed unless DRRT_FLAG_NO_ZERO
+ * Backward: gradient of sum(grad_image * image) w.r.t. (x, v) -- what torch.autograd yields through
+ * the reference's generate_sensor; grad_x, grad_v are (n,3) fp32 outputs (the seed of backtrace).  */
+DRRT_API int drrt_sensor_splat_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                          const float plane_p[3], const float plane_n[3], const float t1[3], const float t2[3],
+                          int res, float span, float* image, unsigned flags, void* stream);
+DRRT_API int drrt_sensor_splat_bwd_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                              const float plane_p[3], const float plane_n[3], const float t1[3], const float t2[3],
+                              int res, float span, const float* grad_image, float* grad_x, float* grad_v,
+                              void* stream);
+
 /* ---- profiling aid (bench.py; no counterpart in the reference) --------------------------------
  * After drrt_profile_begin(capacity) every march call records a HIP event pair on its stream
  * around each kernel it launches (no synchronisation).  drrt_profile_collect() waits for the

@@ -18,6 +18,9 @@ helpers -- plus the CPU oracle:
   fuel_injection.npz   data/fuel_injection_64.npy (float64, F-order) cast to fp32 and padded to 65^3
                        as core/fuel_injection_opt.py:40-43 does; forward exit rays from the oracle
 
+  sensor_splat.npz     core/sensor.py generate_sensor (:5-28) and torch.autograd through it, RUN AS IS in
+                       float64 -> pins the sensor image splat and its backward
+
 Only DATA is stored (inputs and expected outputs); no reference source text.
 """
 import os
@@ -134,9 +137,37 @@ def fuel_injection():
     save("fuel_injection.npz", vol=vol, h=h, ds=ds, x=x, v=v, xt=o["xt"], vt=o["vt"], steps=o["steps"])
 
 
+def sensor_splat():
+    """core/sensor.py generate_sensor (+ torch.autograd) RUN AS IS, float64, on CPU."""
+    torch.manual_seed(3)
+    out = {}
+    for tag, res, with_t, with_e in (("a", 16, True, True), ("b", 33, False, False)):
+        N, span = 1200, 2.0
+        x = torch.rand(N, 3, dtype=torch.float64) * span
+        x[:, 1] = span * 1.01
+        v = torch.randn(N, 3, dtype=torch.float64) * 0.3
+        v[:, 1] = 1.0
+        e = (torch.rand(N, dtype=torch.float64) + 0.5) if with_e else 1.0
+        p = torch.tensor([[span / 2, span * 1.2, span / 2]], dtype=torch.float64)
+        n = torch.tensor([[0.1, 1.0, 0.05]], dtype=torch.float64)
+        n = n / n.norm()
+        t = torch.tensor([[0.0, 0.0, 1.0]], dtype=torch.float64) if with_t else None
+        x.requires_grad_(True); v.requires_grad_(True)
+        img = ref_sensor.generate_sensor((x, v), e, (p, n), res, span, t)
+        gI = torch.randn_like(img)
+        (img * gI).sum().backward()
+        out.update({f"{tag}_x": x.detach().numpy(), f"{tag}_v": v.detach().numpy(),
+                    f"{tag}_e": np.asarray(e.numpy() if with_e else e), f"{tag}_p": p.numpy(), f"{tag}_n": n.numpy(),
+                    f"{tag}_t": (t.numpy() if with_t else np.zeros((0, 3))), f"{tag}_res": res, f"{tag}_span": span,
+                    f"{tag}_img": img.detach().numpy(), f"{tag}_gI": gI.numpy(),
+                    f"{tag}_gx": x.grad.numpy(), f"{tag}_gv": v.grad.numpy()})
+    save("sensor_splat.npz", **out)
+
+
 if __name__ == "__main__":
     getlinear_grid()
     getlinear_cable()
     luneburg_cube()
     ad_vs_adjoint()
     fuel_injection()
+    sensor_splat()

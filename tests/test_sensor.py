@@ -1,0 +1,85 @@
+"""Sensor image splat (SURVEY 8.8 "next" row 1).  The fixture tests/golden/sensor_splat.npz was produced
+by RUNNING the reference's own core/sensor.py generate_sensor and torch.autograd through it (float64),
+so for this row parity is pinned by the reference itself.
+  CPU tier: the numpy restatement (oracle/sensor_ref.py) reproduces the fixture to rounding.
+  GPU tier: the fused HIP kernels (through the C ABI / the autograd Function) reproduce the fixture
+            and, at BASELINE size (1M rays, 512^2 sensor), the restatement and conservation laws."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sensor_splat.npz")
+
+
+def _case(z, tag):
+    t = z[f"{tag}_t"]
+    e = z[f"{tag}_e"]
+    return dict(x=z[f"{tag}_x"], v=z[f"{tag}_v"], e=(e if e.ndim else float(e)), p=z[f"{tag}_p"], n=z[f"{tag}_n"],
+                t=(t if t.size else None), res=int(z[f"{tag}_res"]), span=float(z[f"{tag}_span"]),
+                img=z[f"{tag}_img"], gI=z[f"{tag}_gI"], gx=z[f"{tag}_gx"], gv=z[f"{tag}_gv"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_restatement_matches_reference_run(tag):
+    from oracle import sensor_ref as S
+    c = _case(np.load(G), tag)
+    img = S.generate_sensor(c["x"], c["v"], c["e"], c["p"], c["n"], c["res"], c["span"], c["t"])
+    assert np.abs(img - c["img"]).max() < 1e-12
+    gx, gv = S.generate_sensor_backward(c["x"], c["v"], c["e"], c["p"], c["n"], c["res"], c["span"], c["gI"], c["t"])
+    assert np.abs(gx - c["gx"]).max() < 1e-10 * np.abs(c["gx"]).max()
+    assert np.abs(gv - c["gv"]).max() < 1e-10 * np.abs(c["gv"]).max()
+    # every ray lands inside the image here, so energy is conserved up to taps falling off the border
+    assert img.sum() <= (np.abs(c["v"] @ c["n"].reshape(3)) * c["e"]).sum() * (1 + 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_sensor_matches_reference_run(gpu, tag):
+    from adjointnonlinearraytracing_amd import sensor
+    c = _case(np.load(G), tag)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu, torch.float32)
+    x, v = f(c["x"]).requires_grad_(True), f(c["v"]).requires_grad_(True)
+    e = f(c["e"]) if isinstance(c["e"], np.ndarray) else c["e"]
+    t = None if c["t"] is None else f(c["t"])
+    img = sensor.generate_sensor((x, v), e, (f(c["p"]), f(c["n"])), c["res"], c["span"], t)
+    assert img.shape == (c["res"], c["res"])
+    assert cases.rel_l2(img.detach().cpu().numpy(), c["img"]) <= 2e-6
+    (img * f(c["gI"])).sum().backward()
+    assert cases.rel_l2(x.grad.cpu().numpy(), c["gx"]) <= 2e-4       # fp32 tent-weight derivatives
+    assert cases.rel_l2(v.grad.cpu().numpy(), c["gv"]) <= 2e-4
+
+
+@pytest.mark.gpu
+def test_hip_sensor_full_size(gpu):
+    """1M rays onto a 512^2 sensor (BASELINE config 5 shape): vs the float64 restatement on a sub-sample,
+    energy conservation on the full set, gradient check by a directional finite difference."""
+    from adjointnonlinearraytracing_amd import sensor
+    from oracle import sensor_ref as S
+    torch.manual_seed(0)
+    n, res, span = 1 << 20, 512, 1.0
+    x = torch.rand(n, 3, device=gpu) * span * 0.8 + 0.1 * span
+    x[:, 1] = span
+    v = torch.randn(n, 3, device=gpu) * 0.1
+    v[:, 1] = 1.0
+    p = torch.tensor([[span / 2, 1.1 * span, span / 2]], device=gpu)
+    nn = torch.tensor([[0.0, 1.0, 0.0]], device=gpu)
+    tt = torch.tensor([[0.0, 0.0, 1.0]], device=gpu)
+    img = sensor.generate_sensor((x, v), 1.0, (p, nn), res, span, tt)
+    assert abs(float(img.double().sum()) - float(v[:, 1].abs().double().sum())) <= 1e-4 * n   # all taps inside
+    sub = slice(0, 20000)
+    img_s = sensor.generate_sensor((x[sub], v[sub]), 1.0, (p, nn), res, span, tt)
+    ref = S.generate_sensor(x[sub].cpu().numpy(), v[sub].cpu().numpy(), 1.0, p.cpu().numpy(), nn.cpu().numpy(), res, span,
+                            tt.cpu().numpy())
+    assert cases.rel_l2(img_s.cpu().numpy(), ref) <= 1e-4
+    gI = torch.randn(res, res, device=gpu)
+    xs, vs = x[sub].clone().requires_grad_(True), v[sub].clone().requires_grad_(True)
+    (sensor.generate_sensor((xs, vs), 1.0, (p, nn), res, span, tt) * gI).sum().backward()
+    gx, gv = S.generate_sensor_backward(x[sub].cpu().numpy(), v[sub].cpu().numpy(), 1.0, p.cpu().numpy(), nn.cpu().numpy(),
+                                        res, span, gI.cpu().numpy(), tt.cpu().numpy())
+    assert cases.rel_l2(xs.grad.cpu().numpy(), gx) <= 5e-3 and cases.rel_l2(vs.grad.cpu().numpy(), gv) <= 5e-3
+    with pytest.raises(RuntimeError):
+        sensor.generate_sensor((x.cpu(), v.cpu()), 1.0, (p.cpu(), nn.cpu()), res, span, tt.cpu())
