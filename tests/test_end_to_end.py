@@ -1,0 +1,25 @@
+"""GPU tier: the drop-in API in the reference's optimisation flow (core/luneburg_opt.py :33-128 +
+core/optimizer.py :44-84): a coarse-to-fine Adam loop through tracer.BackTracerC must drive the
+focusing loss down -- forward march, plane-intersection loss, autograd into the adjoint march and
+the gradient mask/clamp all have to cooperate for that."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+
+
+@pytest.mark.gpu
+def test_lens_design_loop_reduces_focus_loss(gpu):
+    import luneburg_demo
+    from adjointnonlinearraytracing_amd import drrt
+    drrt.options.check_failed = False
+    drrt.options.sort_rays = True
+    n, hist = luneburg_demo.run(res_list=(9, 17), iters=40, pixels=48, verbose=False)
+    first, last = sum(hist[:3]) / 3, sum(hist[-3:]) / 3
+    assert last < 0.5 * first, (first, last)
+    assert float(n.min()) >= 1.0 and float(n.max()) > 1.005         # a lens formed; clamp respected
+    # the optimised medium is denser in the middle than at the rim (a focusing GRIN profile)
+    c = n.shape[0] // 2
+    assert float(n[c, c, c]) > float(n[c, c, 1])
