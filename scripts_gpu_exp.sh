@@ -1,2 +1,3 @@
 #!/bin/bash
-timeout -k 10 600 python -m pytest tests/test_end_to_end.py -m gpu -q -x 2>&1 | tail -5
+mkdir -p gpurun_out
+timeout -k 10 300 python tools/profile_sweeps.py > gpurun_out/sweeps.txt 2> gpurun_out/sweeps.err; echo rc=$?; cat gpurun_out/sweeps.txt; tail -3 gpurun_out/sweeps.err
