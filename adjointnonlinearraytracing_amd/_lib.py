@@ -53,6 +53,7 @@ SIGNATURES = {
     "drrt_backtrace_cable_f32": (_i, [_vp, _sz, _f, _f, _sz, _vp, _vp, _vp, _vp, _f, _vp] + _tail),
     "drrt_sensor_splat_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _u, _vp]),
     "drrt_sensor_splat_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "drrt_upres_volume_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "drrt_last_order": (_vp, [_vp]),
     "drrt_set_order_hint": (None, [_vp, _sz]),
     "drrt_profile_begin": (_i, [_i]),

@@ -39,13 +39,25 @@ struct Vol {
   float inv_h;          // 1.0f/h   (reference: rcp(h_), src/volume.cpp:128)
   float inv_h2;         // inv_h*inv_h
   float bx, by, bz;     // (float)(res-1)*h : bounds of inbounds/escaped (src/volume.cpp:252-254)
+  unsigned lx, ly, lz;  // res-3 (0 when res < 4): a floor index i with 1 <= i <= res-3 is "strictly interior"
 };
+
+DRRT_HD void vol_finish(Vol& V, float h) {   // derived fields; data, W, H, D must be set
+  V.sy = V.W; V.sz = V.W * V.H;
+  V.inv_h = 1.0f / h; V.inv_h2 = V.inv_h * V.inv_h;
+  V.bx = (float)(V.W - 1) * h; V.by = (float)(V.H - 1) * h; V.bz = (float)(V.D - 1) * h;
+  V.lx = V.W >= 4 ? (unsigned)(V.W - 3) : 0u; V.ly = V.H >= 4 ? (unsigned)(V.H - 3) : 0u;
+  V.lz = V.D >= 4 ? (unsigned)(V.D - 3) : 0u;
+}
 
 struct Cell {
   int base;             // flat index of corner 000
   int ix, iy, iz;       // (clamped) integer coordinates of corner 000
   int ox, oy, oz;       // element offsets to the +x, +y, +z neighbours (0 where clamped)
   float wx, wy, wz;     // fractional weights w0 = pm - floor(pm)  (unclamped, Q11)
+  bool interior;        // every floor index in [1, res-3]: no clamp acts, the 8 taps are distinct, and
+                        // the point is a whole cell away from every face, so whatever the rounding of
+                        // p*inv_h: inbounds(p) is true and escaped(p, .) is false
 };
 
 DRRT_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -79,6 +91,13 @@ DRRT_HD Cell locate(const Vol& V, float px, float py, float pz) {
   float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
   c.wx = fx - flx; c.wy = fy - fly; c.wz = fz - flz;
   int ix = f2i_sat(flx), iy = f2i_sat(fly), iz = f2i_sat(flz);
+  c.interior = ((unsigned)(ix - 1) < V.lx) & ((unsigned)(iy - 1) < V.ly) & ((unsigned)(iz - 1) < V.lz);
+  if (c.interior) {                      // fast path: the clamps below are no-ops here
+    c.base = mad24(iz, V.sz, mad24(iy, V.sy, ix));
+    c.ix = ix; c.iy = iy; c.iz = iz;
+    c.ox = 1; c.oy = V.sy; c.oz = V.sz;
+    return c;
+  }
   int x0 = clampi(ix, 0, V.W - 1), x1 = clampi(ix + 1, 0, V.W - 1);
   int y0 = clampi(iy, 0, V.H - 1), y1 = clampi(iy + 1, 0, V.H - 1);
   int z0 = clampi(iz, 0, V.D - 1), z1 = clampi(iz + 1, 0, V.D - 1);
@@ -204,36 +223,40 @@ DRRT_HD void fwd_init(const Vol& V, FwdState& s) {
   s.esc = false;                                                                      // :62
 }
 
-// `have` = the ray is inside (its gathers are unmasked); then (c, t) are its cell and the 8 taps of
-// the refractive-index grid there -- fetched by the caller from global memory or from an LDS brick.
+// One forward iteration.  In: `c` = cell of the current position (always located, used only when the
+// ray is inside), `t` = the 8 taps there (valid when s.inside).  Out: `c` = cell of the NEW position,
+// reused by the next iteration -- and when that cell is strictly interior the box tests are skipped
+// (inbounds is true and escaped is false there by construction, see Cell::interior).
 template <int MODE>
-DRRT_HD void fwd_step_taps(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s,
-                           bool have, const Cell& c, const Taps& t) {
+DRRT_HD void fwd_step_c(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s, Cell& c, const Taps& t) {
   float n = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-  if (have) {                                                               // masked gather (Q4)
+  if (s.inside) {                                                           // masked gather (Q4)
     Sample q = interp<false>(t, c.wx, c.wy, c.wz);
     n = q.n; gx = q.gx * V.inv_h; gy = q.gy * V.inv_h; gz = q.gz * V.inv_h;
   }
   const float dsn = ds * n;
   s.vx = fmaf(dsn, gx, s.vx); s.vy = fmaf(dsn, gy, s.vy); s.vz = fmaf(dsn, gz, s.vz);   // :70
   s.x = fmaf(ds, s.vx, s.x); s.y = fmaf(ds, s.vy, s.y); s.z = fmaf(ds, s.vz, s.z);      // :71
-  bool cur_inside;
+  c = locate(V, s.x, s.y, s.z);
+  bool cur_inside, esc_now = false;
   if (MODE == 2) {                                                          // :287-288
     float d = 0.f;
-    if (s.inside) {
-      Cell c2 = locate(V, s.x, s.y, s.z);
-      d = interp<false>(fetch(sdf, c2), c2.wx, c2.wy, c2.wz).n;
-    }
+    if (s.inside) d = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n;
     cur_inside = d < 0.f;
+    if (!c.interior) esc_now = escaped(V, s.x, s.y, s.z, s.vx, s.vy, s.vz);
   } else {
-    cur_inside = inbounds(V, s.x, s.y, s.z);                                // :73
+    cur_inside = true;
+    if (!c.interior) {
+      cur_inside = inbounds(V, s.x, s.y, s.z);                              // :73
+      esc_now = escaped(V, s.x, s.y, s.z, s.vx, s.vy, s.vz);                // :76
+    }
     if (MODE == 1) {                                                        // :144-145
       float d = dot3(s.x - s.aux0, s.y - s.aux1, s.z - s.aux2, s.aux3, s.aux4, s.aux5);
       cur_inside = cur_inside & !(d > 0.f);
     }
   }
   const bool cross = s.inside & !cur_inside;                                // :74
-  s.esc = s.esc | cross | escaped(V, s.x, s.y, s.z, s.vx, s.vy, s.vz);      // :75-76
+  s.esc = s.esc | cross | esc_now;                                          // :75-76
   if (MODE == 3) {                                                          // :216-227
     float ex = s.x - s.aux0, ey = s.y - s.aux1, ez = s.z - s.aux2;
     float cur = dot3(ex, ey, ez, ex, ey, ez);
@@ -245,15 +268,11 @@ DRRT_HD void fwd_step_taps(const Vol& V, const float* __restrict__ sdf, float ds
 }
 
 template <int MODE>
-DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s) {
-  Cell c; Taps t;
-  c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0; c.wx = c.wy = c.wz = 0.f;
+DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s, Cell& c) {
+  Taps t;
   t.v000 = t.v100 = t.v010 = t.v110 = t.v001 = t.v101 = t.v011 = t.v111 = 0.f;
-  if (s.inside) {
-    c = locate(V, s.x, s.y, s.z);
-    t = fetch(V.data, c);
-  }
-  fwd_step_taps<MODE>(V, sdf, ds, s, s.inside, c, t);
+  if (s.inside) t = fetch(V.data, c);
+  fwd_step_c<MODE>(V, sdf, ds, s, c, t);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -284,7 +303,8 @@ DRRT_HD bool adj_step(const Vol& V, const float* __restrict__ sdf, float ds, flo
   const float n = q.n, gx = q.gx * V.inv_h, gy = q.gy * V.inv_h, gz = q.gz * V.inv_h;
   const float mdsn = -ds * n;
   s.vx = fmaf(mdsn, gx, s.vx); s.vy = fmaf(mdsn, gy, s.vy); s.vz = fmaf(mdsn, gz, s.vz); // :423
-  bool active = !escaped(V, s.x, s.y, s.z, -s.vx, -s.vy, -s.vz);                        // :425
+  bool active = true;
+  if (!c.interior) active = !escaped(V, s.x, s.y, s.z, -s.vx, -s.vy, -s.vz);            // :425
   if (MODE == 1) {                                                                      // :488-497
     bool now_out = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n >= 0.f;
     active = active & !((!s.outside) & now_out);
@@ -418,14 +438,12 @@ DRRT_HD RayOut trace_ray(const Vol& V, const float* __restrict__ sdf, float ds, 
     s.aux3 = pln_d[0]; s.aux4 = pln_d[1]; s.aux5 = pln_d[2];
   }
   fwd_init(V, s);
+  Cell c = locate(V, s.x, s.y, s.z);
   bool act = true;
-  if (MODE == 2) {                                                        // src/tracer.cpp:276-277
-    Cell c = locate(V, s.x, s.y, s.z);
-    act = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n < 0.f;
-  }
+  if (MODE == 2) act = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n < 0.f;   // src/tracer.cpp:276-277
   unsigned steps = 0;
   for (int it = 0; it < max_steps; ++it) {
-    fwd_step<MODE>(V, sdf, ds, s);
+    fwd_step<MODE>(V, sdf, ds, s, c);
     ++steps;
     if (s.esc) break;                                                     // per-ray form of :82
   }
@@ -447,9 +465,10 @@ DRRT_HD RayOut target_ray_a(const Vol& V, float ds, int max_steps, const float p
   float ex = s.x - tg[0], ey = s.y - tg[1], ez = s.z - tg[2];
   s.aux3 = dot3(ex, ey, ez, ex, ey, ez);                                  // src/tracer.cpp:200
   fwd_init(V, s);
+  Cell c = locate(V, s.x, s.y, s.z);
   unsigned steps = 0;
   for (int it = 0; it < max_steps; ++it) {
-    fwd_step<3>(V, nullptr, ds, s);
+    fwd_step<3>(V, nullptr, ds, s, c);
     ++steps;
     if (s.esc) break;
   }

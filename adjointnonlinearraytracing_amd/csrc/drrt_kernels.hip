@@ -190,15 +190,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
     }
   }
   fwd_init(V, s);
+  Cell c = locate(V, s.x, s.y, s.z);
   int wox = -(1 << 28), woy = -(1 << 28), woz = -(1 << 28);     // no brick yet
   int cooldown = 0;
   unsigned steps = 0;
   for (int it = 0; it < a.max_steps; ++it) {
     if (!__any(live)) break;                                                // wave-uniform exit
     const bool need = live & s.inside;                                      // lanes that gather this step
-    Cell c;
-    c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0; c.wx = c.wy = c.wz = 0.f;
-    if (need) c = locate(V, s.x, s.y, s.z);
     const bool regular = (c.ox == 1) & (c.oy == V.sy) & (c.oz == V.sz);
     int lidx;
     bool inw = need & regular & nwin_local(wox, woy, woz, c, lidx);
@@ -230,7 +228,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
       tp.v000 = tp.v100 = tp.v010 = tp.v110 = tp.v001 = tp.v101 = tp.v011 = tp.v111 = 0.f;
       if (inw) tp = fetch_lds(nw, lidx);
       else if (need) tp = fetch(V.data, c);
-      fwd_step_taps<MODE>(V, nullptr, a.ds, s, need, c, tp);
+      fwd_step_c<MODE>(V, nullptr, a.ds, s, c, tp);
       ++steps;
       if (s.esc) live = false;                                              // per-ray form of :82
     }
@@ -813,9 +811,7 @@ static int make_vol(const float* rif, long long nvox, const int res[3], float h,
   if (res[0] >= (1 << 24) || res[1] >= (1 << 24) || res[2] >= (1 << 24) || (long long)res[0] * res[1] >= (1 << 24))
     return fail(DRRT_ERR_ARG, "grid extents too large for 24-bit index arithmetic");
   V->data = rif; V->W = res[0]; V->H = res[1]; V->D = res[2];
-  V->sy = res[0]; V->sz = res[0] * res[1];
-  V->inv_h = 1.0f / h; V->inv_h2 = V->inv_h * V->inv_h;
-  V->bx = (float)(res[0] - 1) * h; V->by = (float)(res[1] - 1) * h; V->bz = (float)(res[2] - 1) * h;
+  vol_finish(*V, h);
   return DRRT_OK;
 }
 

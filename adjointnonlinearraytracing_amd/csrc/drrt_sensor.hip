@@ -175,3 +175,61 @@ extern "C" int drrt_sensor_splat_bwd_f32(size_t n, const float* x, const float* 
   hipError_t le = hipGetLastError();
   return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
 }
+
+// =============================================================================================
+// multires up-sampling of a volume (SURVEY.md 8.8 "next" row 3)
+//
+// Reference: core/optimizer.py:7-10 upres_scene -> core/grid.py:318-330 upres_volume: trilinear
+// resampling of the (R,R,R) volume at linspace(0,1,S)^3 through Grid.GetLinear (:227-273), carried
+// out in float64 and cast back.  The reference materialises an (S^3, 3) float64 point list plus ~20
+// (S^3, 8)-sized temporaries (several GB at S = 256); this is one pass, one thread per output voxel.
+// =============================================================================================
+namespace drrt {
+
+__global__ void __launch_bounds__(256) k_upres(const float* __restrict__ src, int r0, int r1, int r2,
+                                               float* __restrict__ dst, int s0, int s1, int s2) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)s0 * s1 * s2;
+  if (i >= total) return;
+  const int k = (int)(i % s2), j = (int)((i / s2) % s1), m = (int)(i / ((size_t)s2 * s1));
+  const int idx[3] = {m, j, k}, sn[3] = {s0, s1, s2};
+  const int rr = r0;                                   // the reference clips every axis with res[0] (grid.py:242)
+  const double h = 1.0 / (double)(rr > 1 ? rr - 1 : 1);   // grid.py:319-320
+  int i0[3], i1[3]; double w[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    // torch.linspace(0, 1, s): step*i for the first half, 1 - step*(s-1-i) for the second
+    const double step = sn[a] > 1 ? 1.0 / (double)(sn[a] - 1) : 0.0;
+    const double x = (idx[a] < sn[a] / 2) ? step * idx[a] : 1.0 - step * (double)(sn[a] - 1 - idx[a]);
+    const double nx = x / h;                           // grid.py:232
+    const double fl = floor(nx);
+    double ww = nx - fl; ww = ww < 0.0 ? 0.0 : (ww > 1.0 ? 1.0 : ww);   // :235
+    w[a] = ww;
+    const int b = (int)fl;
+    i0[a] = min(max(b, 0), rr - 1); i1[a] = min(max(b + 1, 0), rr - 1);  // :243
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int a0 = (c & 4) ? i1[0] : i0[0], a1 = (c & 2) ? i1[1] : i0[1], a2 = (c & 1) ? i1[2] : i0[2];
+    const double ww = ((c & 4) ? w[0] : 1.0 - w[0]) * ((c & 2) ? w[1] : 1.0 - w[1]) * ((c & 1) ? w[2] : 1.0 - w[2]);
+    acc += ww * (double)src[((size_t)a0 * r1 + a1) * r2 + a2];
+  }
+  dst[i] = (float)acc;
+}
+
+}  // namespace drrt
+
+extern "C" int drrt_upres_volume_f32(const float* src, const int src_shape[3], float* dst, const int dst_shape[3],
+                                     void* stream) {
+  if (!src || !dst || !src_shape || !dst_shape) return sensor_fail(DRRT_ERR_ARG, "null pointer");
+  for (int a = 0; a < 3; ++a)
+    if (src_shape[a] < 1 || dst_shape[a] < 1) return sensor_fail(DRRT_ERR_ARG, "bad shape");
+  if (src_shape[0] != src_shape[1] || src_shape[0] != src_shape[2])
+    return sensor_fail(DRRT_ERR_ARG, "upres_volume expects a cubic source volume (the reference clips all axes with res[0])");
+  const size_t total = (size_t)dst_shape[0] * dst_shape[1] * dst_shape[2];
+  hipLaunchKernelGGL(k_upres, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     src_shape[0], src_shape[1], src_shape[2], dst, dst_shape[0], dst_shape[1], dst_shape[2]);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}

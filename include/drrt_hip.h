@@ -201,6 +201,13 @@ DRRT_API int drrt_sensor_splat_bwd_f32(size_t n, const float* x, const float* v,
                               int res, float span, const float* grad_image, float* grad_x, float* grad_v,
                               void* stream);
 
+/* ---- multires up-sampling (SURVEY.md 8.8 "next" row 3) --------------------------------------------
+ * core/optimizer.py:7-10 upres_scene / core/grid.py:318-330 upres_volume: trilinear resampling of a
+ * cubic (R,R,R) fp32 volume at linspace(0,1,S) per axis, evaluated in float64 like the reference and
+ * rounded to fp32.  Shapes are HOST pointers to 3 ints in torch order.                            */
+DRRT_API int drrt_upres_volume_f32(const float* src, const int src_shape[3], float* dst, const int dst_shape[3],
+                          void* stream);
+
 /* ---- profiling aid (bench.py; no counterpart in the reference) --------------------------------
  * After drrt_profile_begin(capacity) every march call records a HIP event pair on its stream
  * around each kernel it launches (no synchronisation).  drrt_profile_collect() waits for the

@@ -1,3 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout -k 10 300 python tools/profile_sweeps.py > gpurun_out/sweeps.txt 2> gpurun_out/sweeps.err; echo rc=$?; cat gpurun_out/sweeps.txt; tail -3 gpurun_out/sweeps.err
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; echo "pytest_rc=$?" >> gpurun_out/pytest_gpu.log
+tail -6 gpurun_out/pytest_gpu.log

@@ -21,6 +21,8 @@ helpers -- plus the CPU oracle:
   sensor_splat.npz     core/sensor.py generate_sensor (:5-28) and torch.autograd through it, RUN AS IS in
                        float64 -> pins the sensor image splat and its backward
 
+  upres.npz            core/optimizer.py upres_scene (:7-10) RUN AS IS -> pins the multires up-sampling
+
 Only DATA is stored (inputs and expected outputs); no reference source text.
 """
 import os
@@ -137,6 +139,18 @@ def fuel_injection():
     save("fuel_injection.npz", vol=vol, h=h, ds=ds, x=x, v=v, xt=o["xt"], vt=o["vt"], steps=o["steps"])
 
 
+def upres():
+    """core/optimizer.py upres_scene (-> core/grid.py upres_volume) RUN AS IS."""
+    import optimizer as ref_optimizer
+    torch.manual_seed(5)
+    out = {}
+    for tag, R, S in (("a", 5, 9), ("b", 9, 17), ("c", 17, 24)):
+        n = (1 + 0.5 * torch.rand(R, R, R)).float()
+        up = ref_optimizer.upres_scene(n, S)
+        out.update({f"{tag}_src": n.numpy(), f"{tag}_dst": up.numpy()})
+    save("upres.npz", **out)
+
+
 def sensor_splat():
     """core/sensor.py generate_sensor (+ torch.autograd) RUN AS IS, float64, on CPU."""
     torch.manual_seed(3)
@@ -171,3 +185,4 @@ if __name__ == "__main__":
     ad_vs_adjoint()
     fuel_injection()
     sensor_splat()
+    upres()

@@ -15,9 +15,8 @@ using namespace drrt;
 
 static Vol make_vol(const float* data, const int res[3], float h) {
   Vol V;
-  V.data = data; V.W = res[0]; V.H = res[1]; V.D = res[2]; V.sy = res[0]; V.sz = res[0] * res[1];
-  V.inv_h = 1.0f / h; V.inv_h2 = V.inv_h * V.inv_h;
-  V.bx = (float)(res[0] - 1) * h; V.by = (float)(res[1] - 1) * h; V.bz = (float)(res[2] - 1) * h;
+  V.data = data; V.W = res[0]; V.H = res[1]; V.D = res[2];
+  vol_finish(V, h);
   return V;
 }
 static int max3(const int r[3]) { return r[0] > r[1] ? (r[0] > r[2] ? r[0] : r[2]) : (r[1] > r[2] ? r[1] : r[2]); }
