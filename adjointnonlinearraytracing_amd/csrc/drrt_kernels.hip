@@ -667,33 +667,35 @@ __global__ void __launch_bounds__(kBlock) k_trace_cable(CableArgs a) {
 }
 
 __global__ void __launch_bounds__(kBlock) k_backtrace_cable(CableArgs a) {
-  extern __shared__ float s_mem[];
+  // LDS: the profile (floats) followed by the gradient accumulators (doubles: ds_add_f64 is ~25x
+  // cheaper than ds_add_f32 on gfx950, tools/lds_atomic_bench.hip, and sums are more accurate)
+  extern __shared__ double s_mem64[];
   const bool use_lds = a.rres <= kCableMaxRes;
-  float* s_prof = s_mem;
-  float* s_grad = s_mem + (use_lds ? a.rres : 0);
+  double* s_grad = s_mem64;
+  float* s_prof = reinterpret_cast<float*>(s_mem64 + (use_lds ? a.rres : 0));
   if (use_lds) {
-    for (int k = threadIdx.x; k < a.rres; k += kBlock) { s_prof[k] = a.rif[k]; s_grad[k] = 0.f; }
+    for (int k = threadIdx.x; k < a.rres; k += kBlock) { s_prof[k] = a.rif[k]; s_grad[k] = 0.0; }
     __syncthreads();
   }
   const Cyl C = make_cyl(use_lds ? s_prof : a.rif, a.rres, a.radius, a.length);
-  float* acc = use_lds ? s_grad : a.grad;
+  float* gacc = a.grad;
   unsigned steps_tot = 0, steps_max = 0;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (size_t)gridDim.x * kBlock) {
     Ray3 p = ld3(a.pos, i), u = ld3(a.vel, i), gxv = ld3(a.dx, i), gvv = ld3(a.dv, i);
     const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
     const float dxx[3] = {gxv.x, gxv.y, gxv.z}, dvv[3] = {gvv.x, gvv.y, gvv.z};
     unsigned steps = cable_backtrace_ray(C, a.ds, a.max_steps, pp, vv, dxx, dvv,
-      [acc, use_lds](int i0, int i1, float a0, float a1) {
-        if (use_lds) { atomicAdd(&acc[i0], a0); atomicAdd(&acc[i1], a1); }      // ds_add_f32
-        else { atomic_add_f32(&acc[i0], a0); atomic_add_f32(&acc[i1], a1); }
+      [s_grad, gacc, use_lds](int i0, int i1, float a0, float a1) {
+        if (use_lds) { atomicAdd(&s_grad[i0], (double)a0); atomicAdd(&s_grad[i1], (double)a1); }   // ds_add_f64
+        else { atomic_add_f32(&gacc[i0], a0); atomic_add_f32(&gacc[i1], a1); }
       });
     steps_tot += steps; steps_max = max(steps_max, steps);
   }
   if (use_lds) {
     __syncthreads();
     for (int k = threadIdx.x; k < a.rres; k += kBlock) {
-      float g = s_grad[k];
-      if (g != 0.f) atomic_add_f32(&a.grad[k], g);
+      double g = s_grad[k];
+      if (g != 0.0) atomic_add_f32(&a.grad[k], (float)g);
     }
   }
   cable_stats(a.stats, steps_tot, steps_max, 0u);
@@ -1055,7 +1057,7 @@ extern "C" int drrt_backtrace_cable_f32(const float* rif, size_t rres, float rad
   a.rif = rif; a.rres = (int)rres; a.radius = radius; a.length = length; a.ds = ds;
   a.max_steps = (int)(4.0f * length / ds);                                   // src/tracer.cpp:544
   a.pos = xt; a.vel = vt; a.dx = dx; a.dv = dv; a.grad = grad; a.stats = stats; a.n = n;
-  size_t lds = (a.rres <= kCableMaxRes) ? 2 * a.rres * sizeof(float) : 0;
+  size_t lds = (a.rres <= kCableMaxRes) ? a.rres * (sizeof(double) + sizeof(float)) : 0;
   hipLaunchKernelGGL(k_backtrace_cable, dim3(cable_grid(n)), dim3(kBlock), lds, s, a);
   LAUNCH_CHECK("k_backtrace_cable");
   return DRRT_OK;

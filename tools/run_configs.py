@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Throughput of every entry point at the BASELINE.json configuration sizes (informational; bench.py
+measures only the metric workload).  Writes one JSON object to stdout.  Needs a GPU.
+
+    python tools/run_configs.py > profiles/r1_configs.json
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+import torch
+
+import bench
+from adjointnonlinearraytracing_amd import drrt, sensor
+
+dev = torch.device("cuda:0")
+drrt.options.check_failed = False
+T = drrt.TracerC()
+
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fn(); torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+out = {}
+
+
+def grid_case(name, R, n, variant="trace"):
+    rif, pos, vel, h, ds = bench.make_workload(R, n, dev, seed=1)
+    span = 1.0
+    res = {}
+    if variant == "trace":
+        t = timed(lambda: T.trace(rif, rif.shape, pos, vel, h, ds))
+        steps = drrt.read_stats()["ray_steps"]
+        xt, vt = T.trace(rif, rif.shape, pos, vel, h, ds)
+        order = drrt.last_order
+        ones = torch.ones_like(xt)
+        ta = timed(lambda: T.backtrace(rif, rif.shape, xt, vt, ones, ones, h, ds, order=order))
+        asteps = drrt.read_stats()["ray_steps"]
+        res = dict(fwd_ms=t * 1e3, fwd_ray_steps=steps, fwd_ray_steps_per_s=steps / t,
+                   adj_ms=ta * 1e3, adj_ray_steps=asteps, adj_ray_steps_per_s=asteps / ta)
+    elif variant == "plane":
+        po = torch.tensor([[0.5, 0.8, 0.5]], device=dev).repeat(n, 1); pd = torch.tensor([[0.0, 1.0, 0.0]], device=dev).repeat(n, 1)
+        t = timed(lambda: T.trace_pln(rif, rif.shape, pos, vel, po, pd, h, ds))
+        steps = drrt.read_stats()["ray_steps"]
+        res = dict(fwd_ms=t * 1e3, fwd_ray_steps=steps, fwd_ray_steps_per_s=steps / t)
+    elif variant == "target":
+        tg = torch.tensor([[0.5, 1.2, 0.5]], device=dev).repeat(n, 1)
+        t = timed(lambda: T.trace_target(rif, rif.shape, pos, vel, tg, h, ds))
+        steps = drrt.read_stats()["ray_steps"]
+        res = dict(fwd_ms=t * 1e3, fwd_ray_steps=steps, fwd_ray_steps_per_s=steps / t)
+    elif variant == "sdf":
+        g = torch.linspace(0, span, R, device=dev)
+        Z, Y, X = torch.meshgrid(g, g, g, indexing="ij")
+        sdf = (torch.sqrt((X - .5) ** 2 + (Y - .5) ** 2 + (Z - .5) ** 2) - 0.45).contiguous()
+        p2 = pos.clone(); p2[:, 1] = 0.5
+        keep = ((p2 - 0.5).norm(dim=1) < 0.4)
+        p2, v2 = p2[keep].contiguous(), vel[keep].contiguous()
+        t = timed(lambda: T.trace_sdf(rif, sdf, rif.shape, p2, v2, h, ds))
+        steps = drrt.read_stats()["ray_steps"]
+        xt, vt = T.trace_sdf(rif, sdf, rif.shape, p2, v2, h, ds)
+        ones = torch.ones_like(xt)
+        ta = timed(lambda: T.backtrace_sdf(rif, sdf, rif.shape, xt, vt, ones, ones, h, ds))
+        asteps = drrt.read_stats()["ray_steps"]
+        res = dict(rays=int(keep.sum()), fwd_ms=t * 1e3, fwd_ray_steps=steps, fwd_ray_steps_per_s=steps / t,
+                   adj_ms=ta * 1e3, adj_ray_steps=asteps, adj_ray_steps_per_s=asteps / ta)
+    out[name] = {"grid": R, "rays": n, **res}
+
+
+grid_case("config0_luneburg_32cube_16k", 32, 128 * 128)
+grid_case("config1_luneburg_128cube_256k", 128, 512 * 512)
+grid_case("config2_like_64cube_1M", 64, 1024 * 1024)
+grid_case("metric_256cube_1M", 256, 1024 * 1024)
+grid_case("config3ii_256cube_4M", 256, 2048 * 2048)
+grid_case("variant_trace_pln_256cube_1M", 256, 1024 * 1024, "plane")
+grid_case("variant_trace_target_256cube_1M", 256, 1024 * 1024, "target")
+grid_case("variant_sdf_256cube_1M", 256, 1024 * 1024, "sdf")
+
+# config 3(i): fibre, 257-sample profile, 4M rays x ~512 steps
+rres, radius = 257, 1.0
+ds = radius / rres / 2
+length = 512 * ds
+prof = torch.sqrt(2.0 - torch.linspace(0, 1, rres) ** 2).to(dev)
+n = 4 * 1024 * 1024
+g = torch.Generator(device="cpu").manual_seed(1)
+ang = torch.rand(n, generator=g) * 2 * np.pi
+rad = 0.9 * radius * torch.sqrt(torch.rand(n, generator=g))
+pos = torch.stack([radius + rad * torch.cos(ang), torch.full((n,), 0.37 * ds), radius + rad * torch.sin(ang)], -1).to(dev)
+vel = torch.randn(n, 3, generator=g) * 0.03; vel[:, 1] = 1.0
+vel = (vel / vel.norm(dim=1, keepdim=True)).to(dev)
+tg = torch.tensor([[radius, 0.75 * length, radius]]).repeat(n, 1).to(dev)
+t = timed(lambda: T.trace_cable(prof, radius, length, pos, vel, tg, ds))
+steps = drrt.read_stats()["ray_steps"]
+xt, vt, d2 = T.trace_cable(prof, radius, length, pos, vel, tg, ds)
+ones = torch.ones_like(xt)
+ta = timed(lambda: T.backtrace_cable(prof, radius, length, xt, vt, ones, ones, ds))
+asteps = drrt.read_stats()["ray_steps"]
+out["config3i_fibre_257_4M"] = dict(rres=rres, rays=n, fwd_ms=t * 1e3, fwd_ray_steps=steps, fwd_ray_steps_per_s=steps / t,
+                                    adj_ms=ta * 1e3, adj_ray_steps=asteps, adj_ray_steps_per_s=asteps / ta)
+
+# config 4 pieces: fp16 ray state + 512^2 sensor
+rif, pos, vel, h, dsv = bench.make_workload(256, 1024 * 1024, dev, seed=2)
+p16, v16 = pos.half(), vel.half()
+t = timed(lambda: T.trace(rif, rif.shape, p16, v16, h, dsv))
+xt, vt = T.trace(rif, rif.shape, pos, vel, h, dsv)
+p = torch.tensor([[0.5, 1.01, 0.5]], device=dev); nn = torch.tensor([[0.0, 1.0, 0.0]], device=dev); tt = torch.tensor([[0.0, 0.0, 1.0]], device=dev)
+ts = timed(lambda: sensor.generate_sensor((xt, vt), 1.0, (p, nn), 512, 1.0, tt))
+out["config4_fp16_trace_and_sensor"] = dict(trace_f16io_ms=t * 1e3, sensor_splat_512_ms=ts * 1e3, rays=1024 * 1024)
+print(json.dumps(out, indent=1))
