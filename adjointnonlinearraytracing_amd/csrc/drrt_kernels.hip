@@ -803,6 +803,14 @@ extern "C" size_t drrt_workspace_bytes(size_t n, unsigned flags) {
 }
 
 // volume ctor checks: src/volume.cpp:31-38 (size) and :123-124 (width/height >= 2)
+static int check_steps(float h, float ds) {
+  // the reference divides by ds and truncates to int (src/tracer.cpp:51): a non-positive or non-finite
+  // step would make that undefined; refuse it instead
+  if (!(h > 0.f) || !(ds > 0.f) || !(h < 3.0e38f) || !(ds < 3.0e38f))
+    return fail(DRRT_ERR_ARG, "h and ds must be positive and finite");
+  return DRRT_OK;
+}
+
 static int make_vol(const float* rif, long long nvox, const int res[3], float h, Vol* V) {
   if (!rif || !res) return fail(DRRT_ERR_ARG, "null rif/res pointer");
   if ((long long)res[0] * res[1] * res[2] != nvox || nvox <= 0)
@@ -812,6 +820,7 @@ static int make_vol(const float* rif, long long nvox, const int res[3], float h,
   if (nvox >= (1LL << 29)) return fail(DRRT_ERR_ARG, "grid too large (>= 2^29 voxels) for 32-bit byte offsets");
   if (res[0] >= (1 << 24) || res[1] >= (1 << 24) || res[2] >= (1 << 24) || (long long)res[0] * res[1] >= (1 << 24))
     return fail(DRRT_ERR_ARG, "grid extents too large for 24-bit index arithmetic");
+  if (!(h > 0.f) || !(h < 3.0e38f)) return fail(DRRT_ERR_ARG, "h and ds must be positive and finite");
   V->data = rif; V->W = res[0]; V->H = res[1]; V->D = res[2];
   vol_finish(*V, h);
   return DRRT_OK;
@@ -861,6 +870,7 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
   hipStream_t s = (hipStream_t)stream;
   TraceArgs a{};
   int rc = make_vol(rif, nvox, res, h, &a.vol); if (rc) return rc;
+  rc = check_steps(h, ds); if (rc) return rc;
   if (n == 0) return zero_stats(stats, s);
   if (!pos || !vel || !xt || !vt) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (MODE == 1 && (!pln_o || !pln_d || !failmask)) return fail(DRRT_ERR_ARG, "null plane/failmask pointer");
@@ -922,6 +932,7 @@ extern "C" int drrt_trace_target_f32(const float* rif, long long nvox, const int
   hipStream_t s = (hipStream_t)stream;
   TargetArgs a{};
   int rc = make_vol(rif, nvox, res, h, &a.vol); if (rc) return rc;
+  rc = check_steps(h, ds); if (rc) return rc;
   if (n == 0) return zero_stats(stats, s);
   if (!pos || !vel || !target || !xt || !vt || !dist2) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
@@ -952,6 +963,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   hipStream_t s = (hipStream_t)stream;
   BackArgs a{};
   int rc = make_vol(rif, nvox, res, h, &a.vol); if (rc) return rc;
+  rc = check_steps(h, ds); if (rc) return rc;
   if (!grad) return fail(DRRT_ERR_ARG, "null grad pointer");
   if (MODE == 1 && !sdf) return fail(DRRT_ERR_ARG, "null sdf pointer");
   if (!(flags & DRRT_FLAG_NO_ZERO)) {                                        // src/tracer.cpp:401-403
@@ -1023,6 +1035,8 @@ extern "C" int drrt_trace_cable_f32(const float* rif, size_t rres, float radius,
   hipStream_t s = (hipStream_t)stream;
   if (!rif) return fail(DRRT_ERR_ARG, "null rif pointer");
   if (rres < 2 || rres > 0x7fffffffULL) return fail(DRRT_ERR_BAD_RES, "volume: invalid resolution!");
+  if (!(radius > 0.f) || !(length > 0.f) || !(ds > 0.f) || !(ds < 3.0e38f))
+    return fail(DRRT_ERR_ARG, "radius, length and ds must be positive and finite");
   int rc = zero_stats(stats, s); if (rc) return rc;
   if (n == 0) return DRRT_OK;
   if (!pos || !vel || !target || !xt || !vt || !dist2) return fail(DRRT_ERR_ARG, "null ray pointer");
@@ -1046,6 +1060,8 @@ extern "C" int drrt_backtrace_cable_f32(const float* rif, size_t rres, float rad
   hipStream_t s = (hipStream_t)stream;
   if (!rif || !grad) return fail(DRRT_ERR_ARG, "null rif/grad pointer");
   if (rres < 2 || rres > 0x7fffffffULL) return fail(DRRT_ERR_BAD_RES, "volume: invalid resolution!");
+  if (!(radius > 0.f) || !(length > 0.f) || !(ds > 0.f) || !(ds < 3.0e38f))
+    return fail(DRRT_ERR_ARG, "radius, length and ds must be positive and finite");
   if (!(flags & DRRT_FLAG_NO_ZERO)) {                                        // src/tracer.cpp:528-530
     hipError_t e = hipMemsetAsync(grad, 0, rres * sizeof(float), s);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(grad)");

@@ -316,6 +316,10 @@ def test_errors_and_edge_cases(gpu, drrt_mod):
         T.trace(rif, (8, 8, 9), x, v, 1.0, 0.5)
     with pytest.raises(RuntimeError, match="invalid resolution"):                # src/volume.cpp:124
         T.trace(torch.ones(8, 1, 1, device=gpu), (1, 1, 8), x, v, 1.0, 0.5)
+    # a non-positive / non-finite step would make the reference's max_steps expression undefined: refused
+    for bad in ((1.0, 0.0), (1.0, -0.5), (0.0, 0.5), (float("nan"), 0.5), (1.0, float("inf"))):
+        with pytest.raises(RuntimeError, match="positive and finite"):
+            T.trace(rif, rif.shape, x, v, *bad)
     # empty ray set
     e = torch.empty(0, 3, device=gpu)
     xt, vt = T.trace(rif, rif.shape, e, e, 1.0, 0.5)
