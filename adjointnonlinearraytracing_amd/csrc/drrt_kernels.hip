@@ -121,15 +121,20 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
 // one batched, independent fill instead of a dependent gather per step -- and reads its taps with
 // ds_read2_b32.  Lanes whose cell is not in the brick gather from global memory as before; the taps
 // are the same floats either way, so results are bit-identical (tests/test_gpu_parity.py).
-// MEASURED (MI355X, 256^3 / 1M rays): 2.4 ms, against 1.5 ms for the default kernel whose four
-// 8-byte pair gathers per step are served by L1/L2 -- the fill (1100 floats every ~14 steps, rows of
-// 10 floats coalesce poorly) and the brick bookkeeping cost more than the texture-addresser work
-// they save.  Kept as an option for workloads with colder caches; NOT the default.
+// MEASURED (MI355X, 256^3 / 1M rays): 1.97 ms (2.4 ms with 10^3 bricks filled by dword loads), against
+// 1.50 ms for the default kernel whose four 8-byte pair gathers per step are served by L1/L2.  The fill
+// is cheap now (four 16-byte loads per lane every ~14 steps), but both kernels run at ~0.014 ms per
+// VALU instruction per step, and the brick bookkeeping (membership test, ballots, re-anchoring) adds
+// ~35 VALU instructions to the 107 of the plain march.  Kept as an option for grids that do not stay
+// cache-resident; NOT the default.
 // ---------------------------------------------------------------------------------------------
-constexpr int kNWin = 10;                                  // brick edge in voxels
-constexpr int kNWinPX = kNWin + 1;                         // padded row pitch
-constexpr int kNWinSY = kNWinPX, kNWinSZ = kNWinPX * kNWin;
-constexpr int kNWinFloats = kNWinSZ * kNWin;               // 1100 floats = 4.3 KiB per wave
+// Brick = 16 (x, the memory-contiguous axis) x 8 x 8 voxels: one row is a 64-byte segment, so the
+// whole brick (4 KiB) is FOUR 16-byte loads per lane -- the wide, coalesced access the texture
+// addresser is good at -- against 4 scattered 8-byte gathers per lane PER STEP without bricks.
+constexpr int kBX = 16, kBY = 8, kBZ = 8;
+constexpr int kBPX = 20;                                   // row pitch in floats (80 B: keeps 16-B alignment, skews banks)
+constexpr int kBSY = kBPX, kBSZ = kBPX * kBY;
+constexpr int kBFloats = kBSZ * kBZ;                       // 1280 floats = 5 KiB per wave
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -138,39 +143,58 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef float __attribute__((ext_vector_type(4), aligned(4))) f4u;     // 16-byte load, 4-byte alignment
+typedef float __attribute__((ext_vector_type(4))) f4a;
+
 __device__ __forceinline__ void nwin_fill(float* nw, int ox, int oy, int oz, const Vol& V, int lane) {
   wave_lds_sync();                           // earlier reads of the old brick are done
-  for (int k = lane; k < kNWinFloats; k += kWave) {
-    const int lx = k % kNWinPX, r = k / kNWinPX;
-    const int ly = r % kNWin, lz = r / kNWin;
+  f4a v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {              // quad q = lane + 64 j  ->  row q/4 = ly + 8 lz, x-quad q%4
+    const int q = lane + kWave * j;
+    const int lx = (q & 3) * 4, row = q >> 2, ly = row & 7, lz = row >> 3;
     const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
-    float v = 0.f;
-    if ((lx < kNWin) & (gx < V.W) & (gy < V.H) & (gz < V.D)) v = V.data[(unsigned)(gz * V.sz + gy * V.sy + gx)];
-    nw[k] = v;
+    v[j] = f4a{0.f, 0.f, 0.f, 0.f};
+    if ((gy < V.H) & (gz < V.D)) {
+      const float* src = V.data + (unsigned)(gz * V.sz + gy * V.sy + gx);
+      if (gx + 3 < V.W) {
+        const f4u u = *reinterpret_cast<const f4u*>(src);
+        v[j] = f4a{u.x, u.y, u.z, u.w};
+      } else {                               // brick sticks out of a narrow grid: element-wise
+        if (gx < V.W) v[j].x = src[0];
+        if (gx + 1 < V.W) v[j].y = src[1];
+        if (gx + 2 < V.W) v[j].z = src[2];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = lane + kWave * j;
+    *reinterpret_cast<f4a*>(nw + (q >> 2) * kBPX + (q & 3) * 4) = v[j];        // ds_write_b128
   }
   wave_lds_sync();
 }
 
 __device__ __forceinline__ bool nwin_local(int wox, int woy, int woz, const Cell& c, int& lidx) {
   const int lx = c.ix - wox, ly = c.iy - woy, lz = c.iz - woz;
-  lidx = lz * kNWinSZ + ly * kNWinSY + lx;
-  return ((unsigned)lx < (unsigned)(kNWin - 1)) & ((unsigned)ly < (unsigned)(kNWin - 1)) &
-         ((unsigned)lz < (unsigned)(kNWin - 1));
+  lidx = lz * kBSZ + ly * kBSY + lx;
+  return ((unsigned)lx < (unsigned)(kBX - 1)) & ((unsigned)ly < (unsigned)(kBY - 1)) &
+         ((unsigned)lz < (unsigned)(kBZ - 1));
 }
 
 __device__ __forceinline__ Taps fetch_lds(const float* nw, int lidx) {
   const float* q = nw + lidx;
   Taps t;
-  t.v000 = q[0];                  t.v100 = q[1];
-  t.v010 = q[kNWinSY];            t.v110 = q[kNWinSY + 1];
-  t.v001 = q[kNWinSZ];            t.v101 = q[kNWinSZ + 1];
-  t.v011 = q[kNWinSZ + kNWinSY];  t.v111 = q[kNWinSZ + kNWinSY + 1];
+  t.v000 = q[0];              t.v100 = q[1];
+  t.v010 = q[kBSY];           t.v110 = q[kBSY + 1];
+  t.v001 = q[kBSZ];           t.v101 = q[kBSZ + 1];
+  t.v011 = q[kBSZ + kBSY];    t.v111 = q[kBSZ + kBSY + 1];
   return t;
 }
 
 template <int MODE>     // 0 = trace, 1 = trace_plane
 __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
-  __shared__ float s_n[kBlock / kWave][kNWinFloats];
+  __shared__ __attribute__((aligned(16))) float s_n[kBlock / kWave][kBFloats];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   float* nw = s_n[wid];
   const Vol& V = a.vol;
@@ -211,10 +235,11 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
       const float dx_ = __shfl(s.vx, ref, kWave), dy_ = __shfl(s.vy, ref, kWave), dz_ = __shfl(s.vz, ref, kWave);
       const float dm = fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f));
       const float fx = 0.5f - 0.4f * (dx_ / dm), fy = 0.5f - 0.4f * (dy_ / dm), fz = 0.5f - 0.4f * (dz_ / dm);
-      int ox = rx - (int)(fx * (float)(kNWin - 2));
-      int oy = ry - (int)(fy * (float)(kNWin - 2));
-      int oz = rz - (int)(fz * (float)(kNWin - 2));
-      ox = max(0, min(ox, V.W - kNWin)); oy = max(0, min(oy, V.H - kNWin)); oz = max(0, min(oz, V.D - kNWin));
+      int ox = rx - (int)(fx * (float)(kBX - 2));
+      int oy = ry - (int)(fy * (float)(kBY - 2));
+      int oz = rz - (int)(fz * (float)(kBZ - 2));
+      ox = max(0, min(ox, V.W - kBX)) & ~3;                                 // 16-byte aligned rows when W % 4 == 0
+      oy = max(0, min(oy, V.H - kBY)); oz = max(0, min(oz, V.D - kBZ));
       wox = __builtin_amdgcn_readfirstlane(ox); woy = __builtin_amdgcn_readfirstlane(oy);
       woz = __builtin_amdgcn_readfirstlane(oz);
       nwin_fill(nw, wox, woy, woz, V, lane);
