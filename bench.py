@@ -128,6 +128,13 @@ def main():
                                                         "to rehearse the multi-rank flow on a 1-GPU box)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL / gloo print banners to the process's stdout from
+    # native code (e.g. "RCCL version : ..."), so file descriptor 1 is pointed at stderr until the final
+    # print and restored just for it.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,7 +148,8 @@ def main():
     local = local % ndev                         # gloo rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun: also with a single rank (rehearses RCCL)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
         if args.backend == "nccl":
@@ -177,11 +185,11 @@ def main():
             lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
         _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),
                                           p(st_a), p(ws), ws.numel(), aflags, stream))
-        if world > 1:
+        if use_dist:
             dist.all_reduce(grad, op=dist.ReduceOp.SUM)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -208,7 +216,7 @@ def main():
     fwd_steps = int(st_f[0].item()); adj_steps = int(st_a[0].item())
     n_failed = int(st_f[1].item())
     t = torch.tensor([elapsed, float(fwd_steps), float(adj_steps)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0]); fwd_total = float(tsum[1]); adj_total = float(tsum[2])
@@ -256,8 +264,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(R, h, ds, rif.cpu().numpy(), pos.cpu().numpy(), vel.cpu().numpy(),
                                                target_seconds=args.cpu_seconds)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    if use_dist:
         dist.destroy_process_group()
 
 
