@@ -370,12 +370,15 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
 // when many lanes hit the same few addresses (measured on MI355X, Luneburg 256^3 / 1M rays: 237 ms
 // for 4.1e9 lane-atomics -- every ray passes through the handful of voxels around the focus).
 // Rays of a wave are spatially coherent (locality sort), so each wave keeps a small box of
-// gradient voxels ("window") in LDS and accumulates its taps there with ds_add_f32; the window is
-// flushed to the global grid -- one atomic per touched voxel, contiguous in x -- only when the
-// rays walk out of it.  Lanes whose cell falls outside the window (incoherent wave, clamped
+// gradient voxels ("window") in LDS and accumulates there (ds_add_f64, fed by per-lane register
+// accumulators that emit one cell face at a time, see below); the window is flushed to the global
+// grid -- one fp32 atomic per touched voxel, contiguous in x -- only when the rays walk out of it.  Lanes whose cell falls outside the window (incoherent wave, clamped
 // boundary cell) fall back to direct global atomics, so the result never depends on the window.
 //
-//   window      kWinX x kWinY x kWinZ voxels of double accumulators, row pitch kWinPX (odd)
+//   window      kWinX x kWinY x kWinZ voxels of double accumulators, row pitch kWinPX (measured:
+//               edge 10 beats 8 and 12; padding the pitch or not is within 1 %)
+//   ablations   BackArgs::experiment (bits 8..15 of `flags`, development only): 1 = no accumulation
+//               at all, 2 = no global atomics, 3 = no LDS adds, 9 = extra histograms
 //   anchor      around the cell of the wave's median contributing lane, shifted towards its
 //               direction of travel (most of the window lies ahead of the rays)
 //   re-anchor   as soon as a contributing lane misses the window (wave-uniform decision); if lanes
