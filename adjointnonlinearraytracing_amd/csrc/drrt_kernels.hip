@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
 //   window      kWinX x kWinY x kWinZ voxels of double accumulators, row pitch kWinPX (measured:
 //               edge 10 beats 8 and 12; padding the pitch or not is within 1 %)
 //   ablations   BackArgs::experiment (bits 8..15 of `flags`, development only): 1 = no accumulation
-//               at all, 2 = no global atomics, 3 = no LDS adds, 9 = extra histograms
+//               at all, 2 = no global atomics, 3 = no LDS adds
 //   anchor      around the cell of the wave's median contributing lane, shifted towards its
 //               direction of travel (most of the window lies ahead of the rays)
 //   re-anchor   as soon as a contributing lane misses the window (wave-uniform decision); if lanes

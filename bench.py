@@ -208,9 +208,6 @@ def main():
     if args.debug_counters:
         off = (ws.numel() - 512) & ~7
         dbg = ws[off:off + 512].view(torch.int64).cpu().tolist()
-        if args.experiment == 9:
-            print(f"[debug] non-regular {dbg[3]}; misses per 32-iteration bucket {dbg[8:24]}; "
-                  f"wave bbox extent histogram (voxels, every 16th step) {dbg[24:56]}", file=sys.stderr)
         print(f"[debug] window flushes {dbg[0]}, ray-steps via LDS window {dbg[1]}, via global fallback {dbg[2]}",
               file=sys.stderr)
     fwd_steps = int(st_f[0].item()); adj_steps = int(st_a[0].item())
