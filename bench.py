@@ -100,7 +100,17 @@ def cpu_baseline(R, h, ds, rif_np, pos_np, vel_np, target_seconds=15.0):
     b = O.backtrace(rif_np, (R, R, R), o["xt"], o["vt"], np.ones_like(o["xt"]), np.ones_like(o["xt"]), h, ds)
     t2 = time.perf_counter()
     steps = int(o["steps"].sum())
+    # all-cores variant of the same port (OpenMP over contiguous ray chunks, private gradient grids):
+    # what a maintainer would get from the host without a GPU; reported beside the 1-thread figure.
+    threads = max(1, min(len(os.sched_getaffinity(0)), 32))
+    n_all = int(min(len(pos_np), n * max(1, threads // 2)))
+    sel_all = np.linspace(0, len(pos_np) - 1, n_all).astype(np.int64)
+    a = O.bench_allcores(rif_np, (R, R, R), pos_np[sel_all], vel_np[sel_all], h, ds, threads)
+    allcores = {"value": a["fwd_steps"] / (a["t_fwd"] + a["t_adj"]), "unit": "ray-steps/s", "cores": a["threads"],
+                "sample": f"{n_all} rays, fwd {a['t_fwd']:.2f}s + adjoint {a['t_adj']:.2f}s (incl. summing "
+                          f"{a['threads']} private grids)"}
     return {
+        "allcores": allcores,
         "value": steps / (t2 - t0), "unit": "ray-steps/s", "cores": 1, "kind": "port",
         "sample": f"{n} of the workload's rays (evenly strided), {R}^3 grid, fwd {t1 - t0:.2f}s + adjoint {t2 - t1:.2f}s, "
                   f"{steps} fwd ray-steps",

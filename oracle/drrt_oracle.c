@@ -164,3 +164,65 @@ EXPORT int oracle_cyl_splat_##SFX(REAL* data, size_t rres, REAL radius, size_t n
 
 DEFINE_API(float, f32)
 DEFINE_API(double, f64)
+
+/* ---- all-cores timing harness (bench.py cpu_baseline_allcores) -----------------------------------
+ * Splits the rays into `nthreads` contiguous chunks; every OpenMP thread runs the SAME fp32 routines
+ * (trace, then backtrace with dx = dv = 1 into a private grid) on its chunk; the private grids are
+ * summed at the end.  Reports wall seconds of the two phases and the forward ray-step count.       */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+EXPORT int oracle_bench_allcores_f32(const float* rif, const int* res, long long nvox, size_t n,
+    const float* pos, const float* vel, float h, float ds, int nthreads, float* grad_out,
+    double* t_fwd, double* t_adj, long long* fwd_steps, int* threads_used) {
+#ifndef _OPENMP
+  (void)rif; (void)res; (void)nvox; (void)n; (void)pos; (void)vel; (void)h; (void)ds; (void)nthreads;
+  (void)grad_out; (void)t_fwd; (void)t_adj; (void)fwd_steps; (void)threads_used;
+  return -9;
+#else
+  if (nthreads < 1) nthreads = omp_get_max_threads();
+  float* xt = (float*)malloc(sizeof(float) * 3 * n);
+  float* vt = (float*)malloc(sizeof(float) * 3 * n);
+  float* ones = (float*)malloc(sizeof(float) * 3 * n);
+  int* steps = (int*)malloc(sizeof(int) * (n ? n : 1));
+  for (size_t i = 0; i < 3 * n; ++i) ones[i] = 1.0f;
+  float* grads = (float*)calloc((size_t)nthreads * (size_t)nvox, sizeof(float));
+  if (!xt || !vt || !ones || !steps || !grads) return -8;
+  int rc_all = 0;
+  double t0 = omp_get_wtime();
+#pragma omp parallel num_threads(nthreads) reduction(|:rc_all)
+  {
+    int t = omp_get_thread_num(), T = omp_get_num_threads();
+    size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
+    long long nf; int it;
+    rc_all |= oracle_trace_f32(rif, res, nvox, hi - lo, pos + 3 * lo, vel + 3 * lo, h, ds, xt + 3 * lo, vt + 3 * lo,
+                               steps + lo, &nf, &it);
+  }
+  double t1 = omp_get_wtime();
+  int used = 0;
+#pragma omp parallel num_threads(nthreads) reduction(|:rc_all)
+  {
+    int t = omp_get_thread_num(), T = omp_get_num_threads();
+    size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
+    long long st;
+    rc_all |= oracle_backtrace_f32(rif, res, nvox, hi - lo, xt + 3 * lo, vt + 3 * lo, ones + 3 * lo, ones + 3 * lo,
+                                   h, ds, 1.0f, grads + (size_t)t * (size_t)nvox, &st);
+#pragma omp single
+    used = T;
+  }
+  if (grad_out) {
+#pragma omp parallel for num_threads(nthreads)
+    for (long long k = 0; k < nvox; ++k) {
+      float acc = 0.f;
+      for (int t = 0; t < used; ++t) acc += grads[(size_t)t * (size_t)nvox + (size_t)k];
+      grad_out[k] = acc;
+    }
+  }
+  double t2 = omp_get_wtime();
+  long long fs = 0;
+  for (size_t i = 0; i < n; ++i) fs += steps[i];
+  *t_fwd = t1 - t0; *t_adj = t2 - t1; *fwd_steps = fs; *threads_used = used;
+  free(xt); free(vt); free(ones); free(steps); free(grads);
+  return rc_all;
+#endif
+}

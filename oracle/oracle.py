@@ -217,6 +217,21 @@ def backtrace_cable(rif, radius, length, xt, vt, dx, dv, ds, dtype=np.float32):
     return dict(grad=grad, steps_total=st.value)
 
 
+def bench_allcores(rif, res, pos, vel, h, ds, nthreads=0):
+    """Timing harness: fp32 trace + backtrace(dx=dv=1) over contiguous ray chunks on `nthreads` OpenMP
+    threads (0 = all), private gradient grids summed at the end.  Returns dict(t_fwd, t_adj, fwd_steps,
+    threads, grad)."""
+    rif = _c(np.asarray(rif).reshape(-1), np.float32)
+    pos, vel = _c(pos, np.float32, 3), _c(vel, np.float32, 3)
+    grad = np.zeros(rif.size, np.float32)
+    tf, ta, fs, th = C.c_double(0), C.c_double(0), C.c_longlong(0), C.c_int(0)
+    rc = lib().oracle_bench_allcores_f32(_p(rif), _p(_res(res)), C.c_longlong(rif.size), C.c_size_t(len(pos)), _p(pos),
+                                         _p(vel), C.c_float(h), C.c_float(ds), C.c_int(nthreads), _p(grad),
+                                         C.byref(tf), C.byref(ta), C.byref(fs), C.byref(th))
+    _check(rc)
+    return dict(t_fwd=tf.value, t_adj=ta.value, fwd_steps=fs.value, threads=th.value, grad=grad)
+
+
 # ----------------------------------------------------------------------------- samplers
 def eval_grad(data, res, h, pts, mask=None, dtype=np.float32):
     """volume::eval_grad (src/volume.cpp:101-181) at points (N,3) -> (n (N,), grad (N,3))."""

@@ -262,3 +262,20 @@ def test_oracle_errors_and_edges(oracle):
     # 1x1x1 volume: constant n, zero gradient (src/volume.cpp:117-121)
     n1, g1 = oracle.eval_grad(np.array([1.5], np.float32), (1, 1, 1), 1.0, x)
     assert np.all(n1 == 1.5) and np.all(g1 == 0)
+
+
+def test_allcores_harness_matches_single_thread(oracle):
+    O = oracle
+    """bench.py's cpu_baseline 'allcores' leg: chunked OpenMP run == the single-thread routines (same
+    per-ray results; the gradient differs only by fp32 summation order across private grids)."""
+    R, span = 33, 1.0
+    h = span / (R - 1)
+    ds = h / 2
+    rif = cases.luneburg(R)
+    pos, vel = cases.plane_rays(3000, span, ds, seed=5)
+    r = O.bench_allcores(rif, rif.shape, pos, vel, h, ds, 3)
+    o = O.trace(rif, rif.shape, pos, vel, h, ds)
+    b = O.backtrace(rif, rif.shape, o["xt"], o["vt"], np.ones_like(pos), np.ones_like(pos), h, ds)
+    assert r["threads"] == 3
+    assert r["fwd_steps"] == int(o["steps"].sum())
+    assert cases.rel_l2(r["grad"], b["grad"]) < 1e-5
