@@ -34,6 +34,7 @@ class Stats(C.Structure):
 STATS_BYTES = C.sizeof(Stats)
 
 _vp, _f, _sz, _u, _ll, _i = C.c_void_p, C.c_float, C.c_size_t, C.c_uint, C.c_longlong, C.c_int
+_d = C.c_double
 _tail = [_vp, _vp, _sz, _u, _vp]          # stats, workspace, workspace_bytes, flags, stream
 
 SIGNATURES = {
@@ -54,6 +55,8 @@ SIGNATURES = {
     "drrt_sensor_splat_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _u, _vp]),
     "drrt_sensor_splat_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "drrt_upres_volume_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "drrt_gen_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "drrt_gen_plane_rays_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drrt_last_order": (_vp, [_vp]),
     "drrt_set_order_hint": (None, [_vp, _sz]),
     "drrt_profile_begin": (_i, [_i]),

@@ -1,0 +1,133 @@
+"""Counterpart of the ray generators of the reference's ``core/source.py`` that feed the march in the
+3-D scripts: ``plane_source3_rand`` (``:54-69``, with ``rotate_pts_to_source`` ``:275-293`` and
+``rotate_ray3`` ``:303-312``), ``rand_rays_in_sphere`` (``:352-357``), ``rand_rays_cube``
+(``:398-412``, plane source) and ``random_rotate_ic`` (``:555-563``).
+
+Same names, argument order and return structure as the reference; the rays are produced ON the
+device by ``csrc/drrt_source.hip`` (all views of a call in three launches, order-preserving disc
+compaction included) instead of on the host followed by an upload.  Keyword-only extras:
+
+* ``device``  -- where the rays are generated (default ``cuda``; there is no CPU path),
+* ``offset``  -- the uniform [0,1) jitter draws, shape ``(nviews, 2*spp, P0, P1)`` (``(2*spp, P0, P1)``
+  for a single view); default ``torch.rand`` on the device.  The reference draws them with the host
+  generator (``:56``), so passing its draws reproduces its rays,
+* ``rotmat``  -- a 3x3 matrix: fuses ``random_rotate_ic`` into the generation (saves a second pass
+  over the 15 floats per ray).
+
+The point / cone / area sources (``:72-272``) are not on the accelerated path: ``rand_rays_cube``
+with ``src_type != 'plane'`` raises ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _view_matrix(angle, vert=False) -> np.ndarray:
+    """rotate_ray3's matrix (core/source.py:303-312), rounded to fp32 exactly as there: the angle keeps
+    its dtype through np.radians / np.cos / np.sin (fp32 for a float32 tensor, fp64 for ints and python
+    floats), the matrix passes through float64 and lands in the rays' dtype (fp32)."""
+    if isinstance(angle, torch.Tensor):
+        angle = angle.detach().cpu().numpy()
+    theta = np.radians(angle)
+    c, s = np.cos(theta), np.sin(theta)
+    c, s = np.asarray(c).reshape(-1)[0], np.asarray(s).reshape(-1)[0]
+    if vert:
+        rn = np.array(((1, 0, 0), (0, c, -s), (0, s, c))).astype(float)
+    else:
+        rn = np.array(((c, -s, 0), (s, c, 0), (0, 0, 1))).astype(float)
+    return rn.astype(np.float32)
+
+
+def rotate_ray3(x, angle, vert=False):
+    """core/source.py:303-312 (plain torch on the tensor's device)."""
+    R = torch.from_numpy(_view_matrix(angle, vert)).to(device=x.device, dtype=x.dtype)
+    return torch.matmul(x, R.T)
+
+
+def _generate(view_mats, pixels, spp, width, circle, sensor_dist, independent, offset, device, rotmat, span):
+    """All views of one call through drrt_gen_plane_rays_f32; returns (x, v, planes), nrays."""
+    dev = torch.device("cuda" if device is None else device)
+    if dev.type != "cuda":
+        raise RuntimeError("ray generation runs on the cuda (ROCm) device only (no CPU path)")
+    nv, p0, p1, spp = len(view_mats), int(pixels[0]), int(pixels[1]), int(spp)
+    with torch.cuda.device(dev):
+        if offset is None:
+            u = torch.rand(nv, 2 * spp, p0, p1, device=dev, dtype=torch.float32)
+        else:
+            u = offset.detach().to(device=dev, dtype=torch.float32).reshape(nv, 2 * spp, p0, p1).contiguous()
+        rots = torch.from_numpy(np.ascontiguousarray(np.stack(view_mats), dtype=np.float32)).to(dev)
+        cap = nv * spp * p0 * p1
+        x = torch.empty(cap, 3, dtype=torch.float32, device=dev)
+        v = torch.empty(cap, 3, dtype=torch.float32, device=dev)
+        planes = torch.empty(cap, 3, 3, dtype=torch.float32, device=dev)
+        counts = torch.empty(nv + 1, dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        ws_bytes = lib.drrt_gen_workspace_bytes(nv, spp, p0, p1)
+        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        if rotmat is None:
+            ic = None
+        else:
+            m = rotmat.detach().cpu().numpy() if isinstance(rotmat, torch.Tensor) else np.asarray(rotmat)
+            ic = (C.c_float * 9)(*np.asarray(m, dtype=np.float64).astype(np.float32).reshape(9).tolist())
+        _lib.check(lib.drrt_gen_plane_rays_f32(
+            C.c_void_p(u.data_ptr()), C.c_void_p(rots.data_ptr()), nv, spp, p0, p1, float(width), float(sensor_dist),
+            int(bool(circle)), int(bool(independent)), ic, float(span if span is not None else width),
+            C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(planes.data_ptr()),
+            C.c_void_p(counts.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        pre = counts.cpu().tolist()               # the one host sync (the reference syncs on its boolean mask too)
+    total = pre[-1]
+    nrays = [pre[i + 1] - pre[i] for i in range(nv)]
+    return (x[:total], v[:total], planes[:total]), nrays
+
+
+def plane_source3_rand(angle, pixels, spp, width, circle=False, xaxis=False, sensor_dist=1.0, independent=False,
+                       *, offset=None, device=None, rotmat=None, span=None):
+    """core/source.py:54-69 -> (x, v, planes)."""
+    iv, _ = _generate([_view_matrix(angle, xaxis)], pixels, spp, width, circle, sensor_dist, independent,
+                      None if offset is None else offset[None], device, rotmat, span)
+    return iv
+
+
+def rand_rays_in_sphere(nviews, im_res, spp, width, angle_span=360, circle=False, xaxis=False, sensor_dist=1.0,
+                        indep=False, *, offset=None, device=None, rotmat=None, span=None):
+    """core/source.py:352-357 -> ((x, v, planes), nrays)."""
+    angles = torch.linspace(0, angle_span, nviews + 1)
+    mats = [_view_matrix(angles[i], xaxis) for i in range(nviews)]
+    return _generate(mats, im_res, spp, width, circle, sensor_dist, indep, offset, device, rotmat, span)
+
+
+def rand_rays_cube(im_res, spp, width, circle=False, src_type='plane', cone_ang=90,
+                   *, offset=None, device=None, rotmat=None, span=None):
+    """core/source.py:398-412 (plane source) -> ((x, v, planes), nrays): four views about z, two about x,
+    sensor_dist = 0."""
+    if src_type != 'plane':
+        raise NotImplementedError("only the plane source is generated on the device (core/source.py:399-400)")
+    angles = torch.linspace(0, 360, 5)
+    vangles = torch.tensor([90, -90])
+    mats = [_view_matrix(angles[i], False) for i in range(len(angles) - 1)]
+    mats += [_view_matrix(va, True) for va in vangles]
+    return _generate(mats, im_res, spp, width, circle, 0.0, False, offset, device, rotmat, span)
+
+
+def random_rotmat():
+    """core/source.py:548-552."""
+    from scipy.spatial.transform import Rotation as R
+    return torch.from_numpy(R.random().as_matrix())
+
+
+def random_rotate_ic(x, v, planes, span, rotmat=None):
+    """core/source.py:555-563 on existing rays (plain torch on their device).  Prefer ``rotmat=`` of the
+    generators above, which applies the same rotation while the rays are being written."""
+    rotmat = (random_rotmat() if rotmat is None else torch.as_tensor(rotmat)).to(device=x.device, dtype=x.dtype)
+    xn = torch.matmul(rotmat, x[..., None] - (span / 2)) + (span / 2)
+    vn = torch.matmul(rotmat, v[..., None])
+    sp = torch.matmul(rotmat, planes[:, 0, :, None] - (span / 2)) + (span / 2)
+    sn = torch.matmul(rotmat, planes[:, 1, :, None])
+    st = torch.matmul(rotmat, planes[:, 2, :, None])
+    return xn.squeeze(-1), vn.squeeze(-1), torch.stack([sp.squeeze(-1), sn.squeeze(-1), st.squeeze(-1)], dim=1)

@@ -1,0 +1,94 @@
+"""CPU restatement of the reference's plane-source ray generators -- TEST INFRASTRUCTURE ONLY.
+
+Follows /root/reference/core/source.py:54-69 (plane_source3_rand), :275-293 (rotate_pts_to_source),
+:303-312 (rotate_ray3), :352-357 (rand_rays_in_sphere), :398-412 (rand_rays_cube, plane source) and
+:555-563 (random_rotate_ic), in numpy float32 with the reference's operation order.  The uniform
+draws are an INPUT (`u`, shape (V, 2*spp, P0, P1)); the reference takes them from torch's host
+generator.  Pinned by tests/golden/source_rays.npz, produced by RUNNING the reference's own functions
+on the same draws in the build container.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F = np.float32
+
+
+def view_matrix(angle, vert=False):
+    """rotate_ray3's R (source.py:304-311); `angle` keeps its dtype through radians/cos/sin."""
+    theta = np.radians(angle)
+    c, s = np.cos(theta), np.sin(theta)
+    c, s = np.asarray(c).reshape(-1)[0], np.asarray(s).reshape(-1)[0]
+    if vert:
+        rn = np.array(((1, 0, 0), (0, c, -s), (0, s, c))).astype(float)
+    else:
+        rn = np.array(((c, -s, 0), (s, c, 0), (0, 0, 1))).astype(float)
+    return rn.astype(F)
+
+
+def _rot(x, R):
+    """x @ R.T accumulated left to right in float32."""
+    out = np.empty_like(x)
+    for k in range(3):
+        out[:, k] = (x[:, 0] * R[k, 0] + x[:, 1] * R[k, 1]) + x[:, 2] * R[k, 2]
+    return out
+
+
+def plane_view(u, R, pixels, spp, width, circle=False, sensor_dist=1.0, independent=False):
+    """One view: u (2*spp, P0, P1) uniforms -> x (n,3), v (n,3), planes (n,3,3), float32."""
+    p0, p1 = int(pixels[0]), int(pixels[1])
+    u = np.asarray(u, F).reshape(2 * spp, p0, p1)
+    w, hw = F(width), F(width / 2)
+    off = u * w                                                           # :56
+    if independent:                                                       # :61-63
+        px = off[:spp] - hw
+        pz = off[spp:] - hw
+    else:                                                                 # :57-58, 65-68
+        r0 = w * (np.arange(p0).astype(F) / F(p0) - F(0.5))
+        r1 = w * (np.arange(p1).astype(F) / F(p1) - F(0.5))
+        px = r0[None, :, None] + off[:spp] / F(p0)
+        pz = r1[None, None, :] + off[spp:] / F(p1)
+    pts = np.stack([px.reshape(-1), np.zeros(px.size, F), pz.reshape(-1)], axis=-1).astype(F)
+    if circle:                                                            # :277-280
+        r = np.sqrt(pts[:, 0] * pts[:, 0] + pts[:, 2] * pts[:, 2])
+        pts = pts[r < hw]
+    n = len(pts)
+    vdir, tdir = R[:, 1].copy(), R[:, 2].copy()                           # R e_y, R e_z
+    x = _rot(pts, R) + hw                                                 # :284
+    x = x - (w * vdir)[None, :] / F(2)                                    # :287
+    plane_x = F(sensor_dist + width / 2) * vdir + hw                      # :290
+    planes = np.broadcast_to(np.stack([plane_x, vdir, tdir])[None], (n, 3, 3)).astype(F).copy()
+    v = np.broadcast_to(vdir[None], (n, 3)).astype(F).copy()
+    return x.astype(F), v, planes
+
+
+def views(u, mats, pixels, spp, width, circle=False, sensor_dist=1.0, independent=False):
+    """Concatenation over views (:352-357 / :398-412): ((x, v, planes), nrays)."""
+    parts = [plane_view(u[i], mats[i], pixels, spp, width, circle, sensor_dist, independent) for i in range(len(mats))]
+    nrays = [len(p[0]) for p in parts]
+    return tuple(np.concatenate(q) for q in zip(*parts)), nrays
+
+
+def sphere_mats(nviews, angle_span=360, xaxis=False):
+    import torch  # torch.linspace's fp32 values are part of the reference's behaviour (:353)
+    angles = torch.linspace(0, angle_span, nviews + 1)
+    return [view_matrix(angles[i].numpy(), xaxis) for i in range(nviews)]
+
+
+def cube_mats():
+    import torch
+    angles = torch.linspace(0, 360, 5)
+    return [view_matrix(angles[i].numpy(), False) for i in range(4)] + \
+           [view_matrix(np.int64(a), True) for a in (90, -90)]
+
+
+def rotate_ic(x, v, planes, span, M):
+    """random_rotate_ic (:555-563) with a given matrix M (float64 -> float32 as in the reference)."""
+    M = np.asarray(M, np.float64).astype(F)
+    hs = F(span / 2)
+    xn = _rot(x - hs, M) + hs
+    vn = _rot(v, M)
+    sp = _rot(planes[:, 0] - hs, M) + hs
+    sn = _rot(planes[:, 1], M)
+    st = _rot(planes[:, 2], M)
+    return xn, vn, np.stack([sp, sn, st], axis=1)

@@ -23,6 +23,11 @@ helpers -- plus the CPU oracle:
 
   upres.npz            core/optimizer.py upres_scene (:7-10) RUN AS IS -> pins the multires up-sampling
 
+  source_rays.npz      core/source.py rand_rays_cube (:398-412), rand_rays_in_sphere (:352-357, circle and
+                       independent variants) and random_rotate_ic (:555-563) RUN AS IS; the torch.rand draws
+                       they consume are recorded by replaying the same host-generator seed
+                       -> pins the device ray generation
+
 Only DATA is stored (inputs and expected outputs); no reference source text.
 """
 import os
@@ -178,6 +183,40 @@ def sensor_splat():
     save("sensor_splat.npz", **out)
 
 
+def source_rays():
+    """core/source.py generators RUN AS IS; `u_*` are the uniforms they drew (same seed replayed)."""
+    out = {}
+    pix, spp, width = (12, 10), 2, 20.0
+
+    def draws(seed, nviews):
+        torch.manual_seed(seed)
+        return torch.stack([torch.rand(2 * spp, *pix) for _ in range(nviews)])
+
+    # rand_rays_cube (circle=True as luneburg_opt.py:62) then random_rotate_ic
+    out["cube_u"] = draws(11, 6).numpy()
+    torch.manual_seed(11)
+    (x, v, pl), nr = ref_source.rand_rays_cube(pix, spp, width, circle=True)
+    out.update(cube_x=x.numpy(), cube_v=v.numpy(), cube_planes=pl.numpy(), cube_nrays=np.array(nr))
+    np.random.seed(4)
+    M = ref_source.random_rotmat()
+    np.random.seed(4)
+    xr, vr, plr = ref_source.random_rotate_ic(x, v, pl, width)
+    out.update(cube_M=M.numpy(), cube_xr=xr.numpy(), cube_vr=vr.numpy(), cube_planes_r=plr.numpy())
+    # rand_rays_in_sphere as image_opt.py:46 (no circle), 5 views over 300 degrees, sensor_dist 0.7
+    out["sph_u"] = draws(12, 5).numpy()
+    torch.manual_seed(12)
+    (x, v, pl), nr = ref_source.rand_rays_in_sphere(5, pix, spp, width, angle_span=300, circle=False, xaxis=False,
+                                                    sensor_dist=0.7)
+    out.update(sph_x=x.numpy(), sph_v=v.numpy(), sph_planes=pl.numpy(), sph_nrays=np.array(nr))
+    # independent samples, about the x axis, disc mask
+    out["ind_u"] = draws(13, 3).numpy()
+    torch.manual_seed(13)
+    (x, v, pl), nr = ref_source.rand_rays_in_sphere(3, pix, spp, 0.3, angle_span=360, circle=True, xaxis=True,
+                                                    sensor_dist=1.0, indep=True)
+    out.update(ind_x=x.numpy(), ind_v=v.numpy(), ind_planes=pl.numpy(), ind_nrays=np.array(nr))
+    save("source_rays.npz", **out)
+
+
 if __name__ == "__main__":
     getlinear_grid()
     getlinear_cable()
@@ -186,3 +225,4 @@ if __name__ == "__main__":
     fuel_injection()
     sensor_splat()
     upres()
+    source_rays()

@@ -1,0 +1,150 @@
+"""Ray generation: core/source.py plane-source generators.
+
+CPU tier: the numpy restatement (oracle/source_ref.py) against tests/golden/source_rays.npz, which was
+produced by RUNNING the reference's rand_rays_cube / rand_rays_in_sphere / random_rotate_ic on
+recorded torch.rand draws.  GPU tier: drrt_gen_plane_rays_f32 (through the python mirror
+adjointnonlinearraytracing_amd.source) against the same fixture and against the restatement on larger
+seeded inputs.
+
+Tolerance: the ray COUNT per view and the ray order are exact; coordinates agree to 4 fp32 ulps of the
+scene width (the two 3x3 products run through the host BLAS in the reference, whose accumulation order
+is not specified; everything else is the same fp32 expression order).
+"""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PIX, SPP = (12, 10), 2
+
+
+def ulps(width):
+    return 4 * np.finfo(np.float32).eps * width
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(G, "source_rays.npz"))
+
+
+@pytest.fixture(scope="module")
+def SR():
+    from oracle import source_ref
+    return source_ref
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    assert np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)), initial=0.0) <= tol
+
+
+# ------------------------------------------------------------------------------------ CPU tier
+def test_restatement_matches_reference_cube(gold, SR):
+    (x, v, pl), nr = SR.views(gold["cube_u"], SR.cube_mats(), PIX, SPP, 20.0, circle=True, sensor_dist=0.0)
+    assert nr == gold["cube_nrays"].tolist()
+    _close(x, gold["cube_x"], ulps(20.0)); _close(v, gold["cube_v"], 0.0); _close(pl, gold["cube_planes"], ulps(20.0))
+    xr, vr, plr = SR.rotate_ic(x, v, pl, 20.0, gold["cube_M"])
+    _close(xr, gold["cube_xr"], ulps(20.0)); _close(vr, gold["cube_vr"], ulps(1.0))
+    _close(plr, gold["cube_planes_r"], ulps(20.0))
+
+
+def test_restatement_matches_reference_sphere_and_independent(gold, SR):
+    (x, v, pl), nr = SR.views(gold["sph_u"], SR.sphere_mats(5, 300), PIX, SPP, 20.0, circle=False, sensor_dist=0.7)
+    assert nr == gold["sph_nrays"].tolist() == [240] * 5
+    _close(x, gold["sph_x"], ulps(20.0)); _close(v, gold["sph_v"], 0.0); _close(pl, gold["sph_planes"], ulps(20.0))
+    (x, v, pl), nr = SR.views(gold["ind_u"], SR.sphere_mats(3, 360, xaxis=True), PIX, SPP, 0.3, circle=True,
+                              sensor_dist=1.0, independent=True)
+    assert nr == gold["ind_nrays"].tolist()
+    _close(x, gold["ind_x"], ulps(0.3)); _close(v, gold["ind_v"], 0.0); _close(pl, gold["ind_planes"], ulps(1.3))
+
+
+# ------------------------------------------------------------------------------------ GPU tier
+@pytest.fixture(scope="module")
+def S():
+    from adjointnonlinearraytracing_amd import source
+    return source
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.gpu
+def test_hip_cube_matches_reference(gold, S):
+    import torch
+    (x, v, pl), nr = S.rand_rays_cube(PIX, SPP, 20.0, circle=True, offset=torch.from_numpy(gold["cube_u"]))
+    assert nr == gold["cube_nrays"].tolist()
+    _close(_np(x), gold["cube_x"], ulps(20.0)); _close(_np(v), gold["cube_v"], 0.0)
+    _close(_np(pl), gold["cube_planes"], ulps(20.0))
+    # fused random_rotate_ic == the reference's two-stage result; and == the stand-alone torch mirror
+    (xr, vr, plr), nr2 = S.rand_rays_cube(PIX, SPP, 20.0, circle=True, offset=torch.from_numpy(gold["cube_u"]),
+                                          rotmat=torch.from_numpy(gold["cube_M"]), span=20.0)
+    assert nr2 == nr
+    _close(_np(xr), gold["cube_xr"], ulps(20.0)); _close(_np(vr), gold["cube_vr"], ulps(1.0))
+    _close(_np(plr), gold["cube_planes_r"], ulps(20.0))
+    x2, v2, pl2 = S.random_rotate_ic(x, v, pl, 20.0, rotmat=torch.from_numpy(gold["cube_M"]))
+    _close(_np(x2), gold["cube_xr"], ulps(20.0)); _close(_np(pl2), gold["cube_planes_r"], ulps(20.0))
+
+
+@pytest.mark.gpu
+def test_hip_sphere_and_independent_match_reference(gold, S):
+    import torch
+    (x, v, pl), nr = S.rand_rays_in_sphere(5, PIX, SPP, 20.0, angle_span=300, sensor_dist=0.7,
+                                           offset=torch.from_numpy(gold["sph_u"]))
+    assert nr == [240] * 5
+    _close(_np(x), gold["sph_x"], ulps(20.0)); _close(_np(v), gold["sph_v"], 0.0)
+    _close(_np(pl), gold["sph_planes"], ulps(20.0))
+    (x, v, pl), nr = S.rand_rays_in_sphere(3, PIX, SPP, 0.3, circle=True, xaxis=True, sensor_dist=1.0, indep=True,
+                                           offset=torch.from_numpy(gold["ind_u"]))
+    assert nr == gold["ind_nrays"].tolist()
+    _close(_np(x), gold["ind_x"], ulps(0.3)); _close(_np(pl), gold["ind_planes"], ulps(1.3))
+    # single view entry point
+    x1, v1, pl1 = S.plane_source3_rand(torch.tensor(0.0), PIX, SPP, 20.0, sensor_dist=0.7,
+                                       offset=torch.from_numpy(gold["sph_u"][0]))
+    _close(_np(x1), gold["sph_x"][:240], ulps(20.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pix,spp,circle", [((512, 512), 1, True), ((257, 131), 3, True), ((64, 64), 4, False),
+                                            ((1, 1), 1, True), ((33, 1), 1, False)])
+def test_hip_matches_restatement_at_size(S, SR, pix, spp, circle):
+    """Compaction across many blocks / ragged tails / several views: bit-exact against the restatement
+    (same fp32 operation order), which the fixture above pins to the reference."""
+    import torch
+    rng = np.random.default_rng(5)
+    u = rng.random((6, 2 * spp, *pix), dtype=np.float32)
+    (x, v, pl), nr = S.rand_rays_cube(pix, spp, 2.0, circle=circle, offset=torch.from_numpy(u))
+    (xo, vo, plo), nro = SR.views(u, SR.cube_mats(), pix, spp, 2.0, circle=circle, sensor_dist=0.0)
+    assert nr == nro
+    assert np.array_equal(_np(x), xo) and np.array_equal(_np(v), vo) and np.array_equal(_np(pl), plo)
+
+
+@pytest.mark.gpu
+def test_hip_generated_rays_feed_the_march(S):
+    """Device-drawn jitter (no offset given): every ray starts inside the cube's bounding sphere, points along
+    its view direction and marches through the tracer."""
+    import torch
+    from adjointnonlinearraytracing_amd import drrt
+    torch.manual_seed(0)
+    span, R = 20.0, 33
+    (x, v, pl), nr = S.rand_rays_cube((64, 64), 1, span, circle=True, rotmat=S.random_rotmat(), span=span)
+    assert sum(nr) == x.shape[0] and x.is_cuda
+    assert torch.allclose(v.norm(dim=1), torch.ones_like(v[:, 0]), atol=1e-5)
+    assert ((x - span / 2).norm(dim=1) <= span / 2 * 1.4143).all()
+    rif = torch.ones(R, R, R, device="cuda")
+    h = span / (R - 1)
+    xt, vt = drrt.TracerC().trace(rif.flatten(), rif.shape, x, v, h, h / 2)
+    assert torch.isfinite(xt).all() and torch.allclose(vt, v, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_source_argument_errors(S):
+    import torch
+    with pytest.raises(NotImplementedError):
+        S.rand_rays_cube((8, 8), 1, 1.0, src_type="point")
+    with pytest.raises(RuntimeError):
+        S.rand_rays_cube((8, 8), 1, -1.0)
+    with pytest.raises(RuntimeError):
+        S.plane_source3_rand(0.0, (8, 8), 1, 1.0, device="cpu")
