@@ -188,3 +188,41 @@ def test_config4_image_caustic_fp16_rays_512_sensor(gpu, D):
     # test_fp16_ray_state_mode).  The descent direction is preserved:
     a, b = grads["f16"][0].double().flatten(), grads["f32"][0].double().flatten()
     assert float((a @ b) / (a.norm() * b.norm())) >= 0.9
+
+
+def test_large_noncubic_grid_512x384x320(gpu, oracle, D):
+    """Beyond BASELINE's sizes: a 63M-voxel NON-cubic grid (flat offsets above 2^24, res = (W,H,D) all
+    different) with oblique rays -- forward bit-exact and adjoint within summation-order tolerance against
+    the oracle on the full (small) ray set; the windowed adjoint equals the direct-atomics kernel."""
+    W, H, Dz = 512, 384, 320
+    h = 1.0 / 511; ds = h / 2
+    rng = np.random.default_rng(9)
+    z, y, x = np.meshgrid(np.linspace(-1, 1, Dz, dtype=np.float32), np.linspace(-1, 1, H, dtype=np.float32),
+                          np.linspace(-1, 1, W, dtype=np.float32), indexing="ij")
+    rif = (1.0 + 0.2 * np.exp(-3.0 * (x * x + y * y + z * z))).astype(np.float32)     # [z,y,x]
+    del x, y, z
+    res = (W, H, Dz)
+    ext = np.array([(W - 1) * h, (H - 1) * h, (Dz - 1) * h], np.float32)
+    n = 20000
+    pos = (rng.uniform(0.02, 0.98, (n, 3)) * ext).astype(np.float32)
+    pos[:, 1] = 0.0
+    vel = rng.normal(0, 0.25, (n, 3)).astype(np.float32); vel[:, 1] = 1.0
+    vel /= np.linalg.norm(vel, axis=1, keepdims=True)
+    T = D.TracerC()
+    rif_d = _t(rif.reshape(-1), gpu)
+    xt, vt = T.trace(rif_d, res, _t(pos, gpu), _t(vel, gpu), h, ds)
+    order = D.last_order
+    with oracle.arith("factored"):
+        o = oracle.trace(rif, res, pos, vel, h, ds, dtype=np.float32)
+    assert np.array_equal(xt.cpu().numpy(), o["xt"]) and np.array_equal(vt.cpu().numpy(), o["vt"])
+    dx = rng.normal(size=(n, 3)).astype(np.float32); dv = rng.normal(size=(n, 3)).astype(np.float32)
+    g = T.backtrace(rif_d, res, xt, vt, _t(dx, gpu), _t(dv, gpu), h, ds, order=order)
+    with oracle.arith("factored"):
+        ob = oracle.backtrace(rif, res, o["xt"], o["vt"], dx, dv, h, ds, dtype=np.float32)
+    assert cases.rel_l2(g.cpu().numpy(), ob["grad"]) <= 2e-5
+    D.options.direct_atomics = True
+    try:
+        g2 = T.backtrace(rif_d, res, xt, vt, _t(dx, gpu), _t(dv, gpu), h, ds)
+    finally:
+        D.options.direct_atomics = False
+    assert cases.rel_l2(g.cpu().numpy(), g2.cpu().numpy()) <= 2e-5
