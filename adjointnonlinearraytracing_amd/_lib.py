@@ -21,6 +21,8 @@ FLAG_NO_ZERO = 4
 FLAG_DIRECT_ATOMICS = 8
 FLAG_DEBUG_COUNTERS = 16
 FLAG_LDS_BRICKS = 32
+FLAG_QUAD_GRID = 64
+FLAG_QUAD_REUSE = 128
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
 
@@ -40,6 +42,7 @@ _tail = [_vp, _vp, _sz, _u, _vp]          # stats, workspace, workspace_bytes, f
 SIGNATURES = {
     # name: (restype, argtypes)   -- must stay in sync with include/drrt_hip.h
     "drrt_workspace_bytes": (_sz, [_sz, _u]),
+    "drrt_workspace_bytes_grid": (_sz, [_sz, _ll, _u]),
     "drrt_last_error": (C.c_char_p, []),
     "drrt_version": (C.c_char_p, []),
     "drrt_trace_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),
@@ -64,7 +67,7 @@ SIGNATURES = {
     "drrt_profile_end": (None, []),
 }
 
-PROF_NAMES = {1: "trace", 2: "backtrace", 3: "sort", 4: "zero"}
+PROF_NAMES = {1: "trace", 2: "backtrace", 3: "sort", 4: "zero", 5: "quad"}
 
 _lib: Optional[C.CDLL] = None
 

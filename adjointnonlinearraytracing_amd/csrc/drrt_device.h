@@ -40,10 +40,12 @@ struct Vol {
   float inv_h2;         // inv_h*inv_h
   float bx, by, bz;     // (float)(res-1)*h : bounds of inbounds/escaped (src/volume.cpp:252-254)
   unsigned lx, ly, lz;  // res-3 (0 when res < 4): a floor index i with 1 <= i <= res-3 is "strictly interior"
+  const float4* quad;   // optional (device only): quad[i] = {n[i], n[i+1], n[i+sy], n[i+sy+1]} for every voxel i
+                        // (clamped at the far x / y faces), built per call by k_build_quad; null = not in use
 };
 
 DRRT_HD void vol_finish(Vol& V, float h) {   // derived fields; data, W, H, D must be set
-  V.sy = V.W; V.sz = V.W * V.H;
+  V.sy = V.W; V.sz = V.W * V.H; V.quad = nullptr;
   V.inv_h = 1.0f / h; V.inv_h2 = V.inv_h * V.inv_h;
   V.bx = (float)(V.W - 1) * h; V.by = (float)(V.H - 1) * h; V.bz = (float)(V.D - 1) * h;
   V.lx = V.W >= 4 ? (unsigned)(V.W - 3) : 0u; V.ly = V.H >= 4 ? (unsigned)(V.H - 3) : 0u;
@@ -137,6 +139,25 @@ DRRT_HD Taps fetch(const float* __restrict__ d, const Cell& c) {
   t.v001 = p[c.oz];         t.v101 = p[c.oz + c.ox];
   t.v011 = p[c.oz + c.oy];  t.v111 = p[c.oz + c.oy + c.ox];
   return t;
+}
+
+// The march's gather is bound by the texture addresser, whose cost is per lane-address and almost flat in
+// the access width up to 16 bytes (tools/gather_bench.hip: four 8-byte gathers 1.00 ms, two 16-byte gathers
+// 0.57 ms for the same 8 corners).  With the quad copy of the grid a strictly interior cell is two 16-byte
+// loads: the (x,y) quad at z0 and the one at z0+1.  Same floats, same Taps -> bit-identical results.
+DRRT_HD Taps fetch_vol(const Vol& V, const Cell& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (V.quad != nullptr && c.interior) {
+    __builtin_assume(c.base >= 0 && c.base < (1 << 29));
+    const float4 a = V.quad[(unsigned)c.base];
+    const float4 b = V.quad[(unsigned)c.base + (unsigned)V.sz];
+    Taps t;
+    t.v000 = a.x; t.v100 = a.y; t.v010 = a.z; t.v110 = a.w;
+    t.v001 = b.x; t.v101 = b.y; t.v011 = b.z; t.v111 = b.w;
+    return t;
+  }
+#endif
+  return fetch(V.data, c);
 }
 
 // n and RAW gradient / mixed partials (not yet multiplied by 1/h, 1/h^2).
@@ -271,7 +292,7 @@ template <int MODE>
 DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s, Cell& c) {
   Taps t;
   t.v000 = t.v100 = t.v010 = t.v110 = t.v001 = t.v101 = t.v011 = t.v111 = 0.f;
-  if (s.inside) t = fetch(V.data, c);
+  if (s.inside) t = fetch_vol(V, c);
   fwd_step_c<MODE>(V, sdf, ds, s, c, t);
 }
 
@@ -299,7 +320,7 @@ DRRT_HD bool adj_step(const Vol& V, const float* __restrict__ sdf, float ds, flo
                       AdjState& s, Cell& c, Corners& w) {
   s.x = fmaf(-ds, s.vx, s.x); s.y = fmaf(-ds, s.vy, s.y); s.z = fmaf(-ds, s.vz, s.z);   // :420
   c = locate(V, s.x, s.y, s.z);
-  const Sample q = interp<true>(fetch(V.data, c), c.wx, c.wy, c.wz);                    // :421-422
+  const Sample q = interp<true>(fetch_vol(V, c), c.wx, c.wy, c.wz);                    // :421-422
   const float n = q.n, gx = q.gx * V.inv_h, gy = q.gy * V.inv_h, gz = q.gz * V.inv_h;
   const float mdsn = -ds * n;
   s.vx = fmaf(mdsn, gx, s.vx); s.vy = fmaf(mdsn, gy, s.vy); s.vz = fmaf(mdsn, gz, s.vz); // :423

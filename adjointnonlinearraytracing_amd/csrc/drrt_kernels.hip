@@ -830,6 +830,44 @@ extern "C" size_t drrt_workspace_bytes(size_t n, unsigned flags) {
   return b;
 }
 
+// Workspace layout: [ sort buffers | trace_target state ][ quad copy of the grid, 16 B per voxel ][ 512 B counters ]
+extern "C" size_t drrt_workspace_bytes_grid(size_t n, long long nvox, unsigned flags) {
+  size_t b = drrt_workspace_bytes(n, flags);
+  if ((flags & DRRT_FLAG_QUAD_GRID) && nvox > 0) b += (size_t)nvox * sizeof(float4);
+  return b + 512;
+}
+
+namespace drrt {
+// quad[i] = {n[i], n[i+1], n[i+W], n[i+W+1]}, neighbours clamped at the far x / y faces (those quads are
+// never read: only strictly interior cells use the copy).  One thread per voxel, 4+16 B of traffic each.
+__global__ void __launch_bounds__(256) k_build_quad(const float* __restrict__ g, float4* __restrict__ q, int W, int H,
+                                                    unsigned nvox) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= nvox) return;
+  const unsigned row = i / (unsigned)W, x = i - row * (unsigned)W, y = row % (unsigned)H;
+  const unsigned x1 = (x + 1u < (unsigned)W) ? 1u : 0u, y1 = (y + 1u < (unsigned)H) ? (unsigned)W : 0u;
+  q[i] = make_float4(g[i], g[i + x1], g[i + y1], g[i + y1 + x1]);
+}
+}  // namespace drrt
+
+// DRRT_FLAG_QUAD_GRID: place (and, unless DRRT_FLAG_QUAD_REUSE, build) the quad copy in the workspace.
+static int maybe_quad(Vol& V, long long nvox, size_t n, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!(flags & DRRT_FLAG_QUAD_GRID)) return DRRT_OK;
+  const size_t off = drrt_workspace_bytes(n, flags), need = off + (size_t)nvox * sizeof(float4) + 512;
+  if (!ws || ws_bytes < need) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_QUAD_GRID (see drrt_workspace_bytes_grid)");
+  if (((uintptr_t)ws + off) % 16 != 0) return fail(DRRT_ERR_ARG, "workspace must be 16-byte aligned for DRRT_FLAG_QUAD_GRID");
+  float4* q = (float4*)((char*)ws + off);
+  if (!(flags & DRRT_FLAG_QUAD_REUSE)) {
+    ProfScope prof(DRRT_PROF_QUAD, s);
+    hipLaunchKernelGGL(drrt::k_build_quad, dim3((unsigned)(((size_t)nvox + 255) / 256)), dim3(256), 0, s, V.data, q, V.W, V.H,
+                       (unsigned)nvox);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "k_build_quad");
+  }
+  V.quad = q;
+  return DRRT_OK;
+}
+
 // volume ctor checks: src/volume.cpp:31-38 (size) and :123-124 (width/height >= 2)
 static int check_steps(float h, float ds) {
   // the reference divides by ds and truncates to int (src/tracer.cpp:51): a non-positive or non-finite
@@ -906,6 +944,7 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
   rc = zero_stats(stats, s); if (rc) return rc;
   rc = maybe_sort(a.vol, h, n, pos, vel, 1.f, flags, ws, ws_bytes, &a.perm, s, io_half); if (rc) return rc;
+  if (!(flags & DRRT_FLAG_LDS_BRICKS)) { rc = maybe_quad(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc; }
   a.io_half = io_half;
   a.sdf = sdf; a.pos = pos; a.vel = vel; a.pln_o = pln_o; a.pln_d = pln_d;
   a.xt = xt; a.vt = vt; a.failmask = failmask; a.stats = stats; a.n = n; a.ds = ds;
@@ -1004,6 +1043,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   if (!xt || !vt || !dx || !dv) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
   rc = maybe_sort(a.vol, h, n, xt, vt, -1.f, flags, ws, ws_bytes, &a.perm, s, io_half); if (rc) return rc;
+  rc = maybe_quad(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc;
   a.io_half = io_half;
   a.sdf = sdf; a.xt = xt; a.vt = vt; a.dx = dx; a.dv = dv; a.grad = grad; a.stats = stats;
   a.n = n; a.ds = ds; a.max_steps = steps_adj(h, res, ds);

@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--lds-bricks", action="store_true", help="forward: opt-in LDS-staged grid bricks")
     ap.add_argument("--no-order-reuse", action="store_true",
                     help="adjoint computes its own visit order instead of reusing the forward's")
+    ap.add_argument("--quad", action="store_true", help="opt-in: build / use the 16-byte quad copy of the grid "
+                                                         "(DRRT_FLAG_QUAD_GRID; forward builds it, adjoint reuses it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-counters", action="store_true", help="print LDS-window counters (stderr)")
     ap.add_argument("--experiment", type=int, default=0, help="development ablation id (0 = product)")
@@ -176,10 +178,14 @@ def main():
     nvox = rif.numel()
     res = (C.c_int * 3)(R, R, R)
     flags = 0 if args.no_sort else _lib.FLAG_SORT_RAYS
+    if args.quad and not args.lds_bricks:
+        flags |= _lib.FLAG_QUAD_GRID                   # forward builds the quad copy, the paired adjoint reuses it
     fflags = flags | (_lib.FLAG_LDS_BRICKS if args.lds_bricks else 0)
     aflags = flags | (_lib.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0)
+    if flags & _lib.FLAG_QUAD_GRID:
+        aflags |= _lib.FLAG_QUAD_REUSE
     aflags |= (_lib.FLAG_DEBUG_COUNTERS if args.debug_counters else 0) | ((args.experiment & 0xff) << 8)
-    ws = torch.empty(int(lib.drrt_workspace_bytes(n, flags)) + 1024, dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, nvox, flags)) + 1024, dtype=torch.uint8, device=dev)
     xt, vt = torch.empty_like(pos), torch.empty_like(vel)
     dx, dv = torch.ones_like(pos), torch.ones_like(vel)          # adjoint seed dx=dv=1 (src/test.cpp:142-144)
     grad = torch.empty(nvox, dtype=torch.float32, device=dev)
@@ -191,7 +197,7 @@ def main():
     def step():
         _lib.check(lib.drrt_trace_f32(p(rif), nvox, res, n, p(pos), p(vel), h, ds, p(xt), p(vt),
                                       p(st_f), p(ws), ws.numel(), fflags, stream))
-        if flags and not args.no_order_reuse:        # adjoint visits rays in the forward's bundle order
+        if (flags & _lib.FLAG_SORT_RAYS) and not args.no_order_reuse:        # adjoint visits rays in the forward's bundle order
             lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
         _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),
                                           p(st_a), p(ws), ws.numel(), aflags, stream))
@@ -235,10 +241,11 @@ def main():
             v = [ms for k, ms in prof if k == name]
             return (sum(v) / len(v)) if v else float("nan")
         ms_fwd, ms_adj, ms_sort, ms_zero = avg("trace"), avg("backtrace"), avg("sort"), avg("zero")
+        ms_quad = avg("quad")
         ach_adj = adj_steps * B_ADJ / (ms_adj * 1e-3) / 1e9
         ach_fwd = fwd_steps * B_FWD / (ms_fwd * 1e-3) / 1e9
         default_cfg = (R == 256 and n == 1024 * 1024 and not args.no_sort and not args.direct_atomics
-                       and not args.experiment)
+                       and not args.experiment and not args.quad and not args.lds_bricks)
         tr_adj = measured_traffic("drrt::k_backtrace_win") if default_cfg else None
         tr_fwd = measured_traffic("drrt::k_trace") if default_cfg else None
         out = {
@@ -254,7 +261,7 @@ def main():
                                    + (", one RCCL all-reduce(sum) of the grid per step" if world > 1 else ""),
                        "grid": R, "rays_per_gpu": n, "fwd_ray_steps_per_gpu": fwd_steps,
                        "adj_ray_steps_per_gpu": adj_steps, "n_failed": n_failed,
-                       "sort_rays": not args.no_sort, "parallelism": f"ray-shard x{world}"},
+                       "sort_rays": not args.no_sort, "quad_grid": bool(flags & _lib.FLAG_QUAD_GRID), "parallelism": f"ray-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "adjoint march (k_backtrace)", "achieved": ach_adj,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_adj / HBM_PEAK_GBS, "traffic": tr_adj and tr_adj["bytes"],
                          "traffic_source": tr_adj and tr_adj["source"],
@@ -265,7 +272,8 @@ def main():
                              "traffic_source": tr_fwd and tr_fwd["source"],
                              "algorithmic_bytes_per_ray_step": B_FWD, "ray_steps_per_launch": fwd_steps,
                              "avg_kernel_ms": ms_fwd},
-            "phase_ms": {"sort_avg": ms_sort, "zero_grid": ms_zero, "trace": ms_fwd, "backtrace": ms_adj},
+            "phase_ms": {"sort_avg": ms_sort, "zero_grid": ms_zero, "quad_copy": None if ms_quad != ms_quad else ms_quad,
+                         "trace": ms_fwd, "backtrace": ms_adj},
             "fwd_only_ray_steps_per_s_per_gpu": fwd_steps / (ms_fwd * 1e-3),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -64,6 +64,15 @@ extern "C" {
                                        read the taps from there instead of gathering from global
                                        memory every step.  Bit-identical results; measured slower than
                                        the default L1-served pair gathers on MI355X   */
+#define DRRT_FLAG_QUAD_GRID    64u  /* trace / trace_pln / trace_sdf / backtrace*: build a "quad" copy of the grid in
+                                       the workspace (16 B per voxel: each voxel with its +x, +y, +x+y neighbours)
+                                       and fetch the 8 corners of a strictly interior cell with two 16-byte loads
+                                       instead of four 8-byte ones.  Bit-identical results.  Needs a 16-byte aligned
+                                       workspace of drrt_workspace_bytes_grid() bytes.  Pays off when the call does
+                                       well over ~6 ray-steps per voxel (the copy costs 20 B of traffic per voxel) */
+#define DRRT_FLAG_QUAD_REUSE  128u  /* with QUAD_GRID: the workspace still holds the quad copy built by the previous
+                                       call (same rif contents, same n, same flags & SORT_RAYS, same workspace) --
+                                       e.g. the adjoint paired with its forward: skip the rebuild                  */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
                                        written to the last 512 bytes of the workspace:
                                        [0] LDS-window flushes, [1] ray-steps accumulated through
@@ -79,6 +88,9 @@ typedef struct drrt_stats {
 
 /* Bytes of device scratch a call over `n` rays may need (0 when flags need none). */
 DRRT_API size_t drrt_workspace_bytes(size_t n, unsigned flags);
+/* Same, for a call on a grid of `nvox` voxels: adds the quad copy when DRRT_FLAG_QUAD_GRID is set and the
+ * 512-byte counter block.  Layout: [sort buffers | trace_target state][quad copy][counters].          */
+DRRT_API size_t drrt_workspace_bytes_grid(size_t n, long long nvox, unsigned flags);
 
 /* Message of the last error on this thread ("" if none). */
 DRRT_API const char* drrt_last_error(void);
@@ -238,6 +250,7 @@ DRRT_API int drrt_gen_plane_rays_f32(const float* u, const float* view_rot, int 
 #define DRRT_PROF_BACKTRACE  2   /* adjoint march kernel                 */
 #define DRRT_PROF_SORT       3   /* entry-voxel keys + radix sort        */
 #define DRRT_PROF_ZERO       4   /* zero-fill of the gradient grid       */
+#define DRRT_PROF_QUAD       5   /* build of the quad copy of the grid   */
 DRRT_API int  drrt_profile_begin(int capacity);
 DRRT_API int  drrt_profile_collect(int* kernel_ids, float* ms, int max_out);
 DRRT_API void drrt_profile_end(void);

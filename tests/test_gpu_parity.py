@@ -130,6 +130,62 @@ def test_lds_bricks_are_bit_identical_to_global_gathers(gpu, drrt_mod, sort):
         assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
 
 
+@pytest.mark.parametrize("sort", [True, False])
+def test_quad_grid_copy_is_bit_identical(gpu, oracle, drrt_mod, sort):
+    """DRRT_FLAG_QUAD_GRID (two 16-byte loads per interior cell from the quad copy) vs the plain grid: the
+    taps are the same floats, so forward results are identical bit for bit and the adjoint differs only by
+    atomic summation order.  Covers cubic and non-cubic grids, the plane / sdf variants, a grid too small to
+    have interior cells, and the paired-adjoint reuse of the copy -- including after ANOTHER grid has been
+    marched in between (the stale copy must not be used)."""
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = sort
+    try:
+        for shape, n in (((65, 65, 65), 6000), ((40, 33, 48), 3000), ((3, 3, 3), 300)):
+            D_, H_, W_ = shape
+            span = 1.0
+            h = span / (max(shape) - 1); ds = h / 2
+            rng = np.random.default_rng(21)
+            rif_np = (1.0 + 0.3 * rng.random(shape, dtype=np.float32)).astype(np.float32)
+            rif = _t(rif_np, gpu)
+            other = _t((1.0 + 0.3 * rng.random(shape, dtype=np.float32)).astype(np.float32), gpu)
+            sdf = _t((rng.random(shape, dtype=np.float32) - 0.7).astype(np.float32), gpu)
+            res = (W_, H_, D_)
+            ext = np.array([(W_ - 1) * h, (H_ - 1) * h, (D_ - 1) * h], np.float32)
+            pos = (rng.uniform(0.02, 0.98, (n, 3)) * ext).astype(np.float32); pos[:, 1] = 0.0
+            vel = rng.normal(0, 0.3, (n, 3)).astype(np.float32); vel[:, 1] = 1.0
+            vel /= np.linalg.norm(vel, axis=1, keepdims=True)
+            po = np.tile((np.array([[0.5, 0.6, 0.5]], np.float32) * ext), (n, 1)).astype(np.float32)
+            pd = np.tile(np.array([[0, 1, 0]], np.float32), (n, 1))
+            dx = rng.normal(size=(n, 3)).astype(np.float32); dv = rng.normal(size=(n, 3)).astype(np.float32)
+            P, V_, PO, PD, DX, DV = (_t(a, gpu) for a in (pos, vel, po, pd, dx, dv))
+            out = {}
+            for quad in (True, False):
+                drrt_mod.options.quad_grid = quad
+                xt, vt = T.trace(rif, res, P, V_, h, ds)
+                st, order = drrt_mod.read_stats(), drrt_mod.last_order
+                g_paired = T.backtrace(rif, res, xt, vt, DX, DV, h, ds, order=order)          # reuses the copy
+                xo, vo = T.trace(other, res, P, V_, h, ds)                                    # another grid in between
+                g_after = T.backtrace(rif, res, xt, vt, DX, DV, h, ds, order=order)           # must rebuild
+                g_plain = T.backtrace(rif, res, xt, vt, DX, DV, h, ds)                        # unpaired: rebuilds
+                xp, vp, fm = T.trace_pln(rif, res, P, V_, PO, PD, h, ds)
+                xs, vs = T.trace_sdf(rif, sdf, res, P, V_, h, ds)
+                gs = T.backtrace_sdf(rif, sdf, res, xs, vs, DX, DV, h, ds)
+                out[quad] = [t.cpu() for t in (xt, vt, xo, vo, xp, vp, fm, xs, vs)] + [st] + \
+                            [t.cpu().numpy() for t in (g_paired, g_after, g_plain, gs)]
+            a, b = out[True], out[False]
+            for k in range(9):
+                assert torch.equal(a[k], b[k]), (shape, k)
+            assert a[9] == b[9]
+            for k in range(10, 14):
+                assert cases.rel_l2(a[k], b[k]) <= 2e-6, (shape, k)
+            with oracle.arith("factored"):
+                o = oracle.trace(rif_np, res, pos, vel, h, ds, dtype=np.float32)
+            assert np.array_equal(a[0].numpy(), o["xt"]) and np.array_equal(a[1].numpy(), o["vt"])
+    finally:
+        drrt_mod.options.quad_grid = False
+        drrt_mod.options.sort_rays = True
+
+
 @pytest.mark.parametrize("kind", ["luneburg", "smooth"])
 def test_window_kernel_equals_direct_atomics(gpu, drrt_mod, kind):
     """The LDS gradient-window kernel (default) and the one-atomic-per-tap kernel
