@@ -445,7 +445,7 @@ DRRT_HD bool cable_adj_step(const Cyl& C, float ds, AdjState& s, int& i0, int& i
 // ---------------------------------------------------------------------------------------------
 // whole-ray drivers shared by the kernels (one ray per lane) and by tests/hostcheck
 // ---------------------------------------------------------------------------------------------
-struct RayOut { float xt[3], vt[3]; float dist2; bool esc, act; unsigned steps; };
+struct RayOut { float xt[3], vt[3]; float dist2; bool esc, act, again; unsigned steps; };
 
 // trace / trace_plane / trace_sdf for ONE ray, per-ray termination (see drrt_kernels.hip header)
 template <int MODE>
@@ -472,7 +472,48 @@ DRRT_HD RayOut trace_ray(const Vol& V, const float* __restrict__ sdf, float ds, 
   if (MODE != 2 && !s.esc) { s.xtx = s.x; s.xty = s.y; s.xtz = s.z; }     // :95 (vt stays, Q6)
   RayOut o;
   o.xt[0] = s.xtx; o.xt[1] = s.xty; o.xt[2] = s.xtz; o.vt[0] = s.vtx; o.vt[1] = s.vty; o.vt[2] = s.vtz;
-  o.dist2 = 0.f; o.esc = s.esc; o.act = act; o.steps = steps;
+  o.dist2 = 0.f; o.esc = s.esc; o.act = act; o.steps = steps; o.again = false;
+  if (MODE == 1 && s.esc) {
+    // The reference keeps marching escaped rays while its global loop runs (:130-160) and records EVERY
+    // inside -> outside transition, so a ray that can come back into {in bounds, not past the plane} may
+    // overwrite its exit record later.  An escaped ray flies straight (its gathers are masked), hence it can
+    // NOT come back when it is outside the box moving away (volume::escaped), or past the plane and not
+    // approaching it.  Anything else -- in practice only a ray that STARTS past the plane and heads back
+    // through it -- is flagged and re-marched over the global loop count by plane_ray_full.
+    const float d = dot3(s.x - s.aux0, s.y - s.aux1, s.z - s.aux2, s.aux3, s.aux4, s.aux5);
+    const float dv = dot3(s.vx, s.vy, s.vz, s.aux3, s.aux4, s.aux5);
+    const bool gone = escaped(V, s.x, s.y, s.z, s.vx, s.vy, s.vz) | ((d > 0.f) & (dv >= 0.f));
+    o.again = !gone;
+  }
+  if (MODE == 2 && s.esc && s.inside) {
+    // trace_sdf: the ray left the BOX (volume::escaped) while the clamped sdf sample still reads negative.  The
+    // reference keeps marching it -- still "inside", still refracted by clamped samples -- and records the
+    // moment the sdf turns non-negative, if its global loop lasts that long (:283-304).  Flag for ray_full<2>.
+    // (Once the sdf sample is non-negative the later ones are masked to 0, so a ray can cross only once.)
+    o.again = true;
+  }
+  return o;
+}
+
+// trace_plane / trace_sdf for ONE ray over exactly `total` iterations of the reference's global loop, no
+// early termination (src/tracer.cpp:130-160, :283-304 as written): for the rays trace_ray flags with `again`.
+template <int MODE>
+DRRT_HD RayOut ray_full(const Vol& V, const float* __restrict__ sdf, float ds, unsigned total, const float p[3],
+                        const float v[3], const float* pln_o, const float* pln_d) {
+  FwdState s;
+  s.x = p[0]; s.y = p[1]; s.z = p[2]; s.vx = v[0]; s.vy = v[1]; s.vz = v[2];
+  s.aux0 = s.aux1 = s.aux2 = s.aux3 = s.aux4 = s.aux5 = 0.f;
+  if (MODE == 1) {
+    s.aux0 = pln_o[0]; s.aux1 = pln_o[1]; s.aux2 = pln_o[2];
+    s.aux3 = pln_d[0]; s.aux4 = pln_d[1]; s.aux5 = pln_d[2];
+  }
+  fwd_init(V, s);
+  Cell c = locate(V, s.x, s.y, s.z);
+  for (unsigned it = 0; it < total; ++it) fwd_step<MODE>(V, sdf, ds, s, c);
+  if (MODE != 2 && !s.esc) { s.xtx = s.x; s.xty = s.y; s.xtz = s.z; }
+  RayOut o;
+  o.xt[0] = s.xtx; o.xt[1] = s.xty; o.xt[2] = s.xtz; o.vt[0] = s.vtx; o.vt[1] = s.vty; o.vt[2] = s.vtz;
+  o.dist2 = 0.f; o.esc = s.esc; o.act = !s.esc; o.steps = total; o.again = false;
   return o;
 }
 

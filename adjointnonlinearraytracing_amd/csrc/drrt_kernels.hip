@@ -83,6 +83,7 @@ struct TraceArgs {
   const void* pos; const void* vel;         // fp32, or half when io_half
   const float* pln_o; const float* pln_d;   // MODE 1
   void* xt; void* vt; uint8_t* failmask;
+  uint8_t* again;              // MODE 2: per-ray "re-march over the global loop count" flags (workspace)
   int io_half;
   const uint32_t* perm;        // nullable: visit order
   drrt_stats* stats;
@@ -108,9 +109,30 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
     steps = r.steps; failed = r.act ? 1u : 0u;
     st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2], a.io_half);
     st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2], a.io_half);
-    if (MODE == 1) a.failmask[i] = r.esc ? 0 : 1;                           // src/tracer.cpp:171
+    if (MODE == 1) a.failmask[i] = (r.esc ? 0 : 1) | (r.again ? 2 : 0);     // src/tracer.cpp:171; bit 1: k_trace_again
+    if (MODE == 2) a.again[i] = r.again ? 1 : 0;
   }
   block_stats(a.stats, steps, failed);
+}
+
+// trace_plane / trace_sdf, second pass: rays flagged by the first pass (failmask bit 1 / `again` byte) are
+// re-marched over the reference's GLOBAL loop count (stats->iters of the first pass), see trace_ray / ray_full.
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_trace_again(TraceArgs a) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  if (MODE == 1 ? !(a.failmask[i] & 2) : !a.again[i]) return;
+  Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
+  const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
+  float po[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
+  if (MODE == 1) {
+    Ray3 o = ld3(a.pln_o, i), d = ld3(a.pln_d, i);
+    po[0] = o.x; po[1] = o.y; po[2] = o.z; pd[0] = d.x; pd[1] = d.y; pd[2] = d.z;
+  }
+  RayOut r = ray_full<MODE>(a.vol, a.sdf, a.ds, a.stats->iters, pp, vv, po, pd);
+  st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2], a.io_half);
+  st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2], a.io_half);
+  if (MODE == 1) a.failmask[i] = r.esc ? 0 : 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -940,11 +962,21 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
   if (n == 0) return zero_stats(stats, s);
   if (!pos || !vel || !xt || !vt) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (MODE == 1 && (!pln_o || !pln_d || !failmask)) return fail(DRRT_ERR_ARG, "null plane/failmask pointer");
+  if ((MODE == 1 || MODE == 2) && !stats) {   // the second pass needs the global loop count: library-owned block
+    static drrt_stats* priv = nullptr;
+    if (!priv) { hipError_t e = hipMalloc((void**)&priv, sizeof(drrt_stats)); if (e != hipSuccess) return fail_hip(e, "hipMalloc(stats)"); }
+    stats = priv;
+  }
   if (MODE == 2 && !sdf) return fail(DRRT_ERR_ARG, "null sdf pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
   rc = zero_stats(stats, s); if (rc) return rc;
   rc = maybe_sort(a.vol, h, n, pos, vel, 1.f, flags, ws, ws_bytes, &a.perm, s, io_half); if (rc) return rc;
   if (!(flags & DRRT_FLAG_LDS_BRICKS)) { rc = maybe_quad(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc; }
+  if (MODE == 2) {                      // n flag bytes, in the slack the workspace keeps after the sort buffers
+    const size_t off = (flags & DRRT_FLAG_SORT_RAYS) ? align_up(sort_workspace_bytes(n), 256) : 0;
+    if (!ws || ws_bytes < off + n) return fail(DRRT_ERR_ARG, "workspace too small for trace_sdf (see drrt_workspace_bytes)");
+    a.again = (uint8_t*)ws + off;
+  }
   a.io_half = io_half;
   a.sdf = sdf; a.pos = pos; a.vel = vel; a.pln_o = pln_o; a.pln_d = pln_d;
   a.xt = xt; a.vt = vt; a.failmask = failmask; a.stats = stats; a.n = n; a.ds = ds;
@@ -957,6 +989,10 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
       hipLaunchKernelGGL(k_trace_win<(MODE == 2 ? 0 : MODE)>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
   }
   LAUNCH_CHECK("k_trace");
+  if (MODE == 1 || MODE == 2) {
+    hipLaunchKernelGGL(k_trace_again<(MODE == 2 ? 2 : 1)>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    LAUNCH_CHECK("k_trace_again");
+  }
   return DRRT_OK;
 }
 

@@ -147,7 +147,9 @@ DRRT_API int drrt_trace_target_f32(const float* rif, long long nvox, const int r
                           drrt_stats* stats, void* workspace, size_t workspace_bytes,
                           unsigned flags, void* stream);
 
-/* Tracer::trace_sdf -- src/tracer.cpp:244-310, TracerC.trace_sdf (src/drrt.cpp:53).            */
+/* Tracer::trace_sdf -- src/tracer.cpp:244-310, TracerC.trace_sdf (src/drrt.cpp:53).
+ * Always needs a workspace of drrt_workspace_bytes(n, flags) bytes (n flag bytes for the second pass that
+ * reproduces the reference's global-loop behaviour of rays leaving the box while still sdf-inside).  */
 DRRT_API int drrt_trace_sdf_f32(const float* rif, const float* sdf, long long nvox, const int res[3],
                        size_t n, const float* pos, const float* vel, float h, float ds,
                        float* xt, float* vt,

@@ -76,3 +76,38 @@ def step_flip_report(xt, vt, xt_ref, vt_ref, ds, tol):
     step = np.linalg.norm(ds * vt_ref[bad].astype(np.float64), axis=1)
     explained = np.abs(d[bad] - step) < 10 * tol + 1e-3 * step
     return float(bad.mean()), float((bad.sum() - explained.sum()) / len(d))
+
+
+def fuzz_config(seed):
+    """Seeded nasty configuration for the differential fuzz tests (tests/test_gpu_fuzz.py on the GPU,
+    tests/test_hostcheck.py::test_fuzz_hostcheck on the host build of the per-ray code)."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H, D = (int(v) for v in rng.integers(2, 25, 3))
+    if seed % 7 == 0:
+        D = 2
+    h = float(np.float32(rng.uniform(0.05, 2.0)))
+    ds = float(np.float32(h * rng.uniform(0.2, 1.7)))
+    if seed % 3 == 0:
+        rif = 1.0 + 0.5 * rng.random((D, H, W))
+    else:
+        z, y, x = np.meshgrid(np.linspace(0, 1, D), np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+        rif = 1.0 + 0.3 * np.sin(3 * x + 1) * np.cos(2 * y) + 0.2 * z * z
+    rif = rif.astype(np.float32)
+    sdf = (rng.random((D, H, W)) - 0.6).astype(np.float32)
+    n = 600
+    ext = np.array([(W - 1) * h, (H - 1) * h, (D - 1) * h])
+    pos = rng.uniform(-0.15, 1.15, (n, 3)) * ext
+    face = rng.integers(0, 6, n)
+    onface = rng.random(n) < 0.3                       # exactly on a face
+    for i in np.nonzero(onface)[0]:
+        a = face[i] // 2
+        pos[i, a] = 0.0 if face[i] % 2 == 0 else ext[a]
+    vel = rng.normal(size=(n, 3))
+    vel /= np.linalg.norm(vel, axis=1, keepdims=True)
+    vel *= rng.uniform(0.5, 1.5, (n, 1))
+    vel[rng.random(n) < 0.02] = 0.0                    # rays that never move
+    return dict(res=(W, H, D), h=h, ds=ds, rif=rif, sdf=sdf, pos=pos.astype(np.float32), vel=vel.astype(np.float32),
+                dx=rng.normal(size=(n, 3)).astype(np.float32), dv=rng.normal(size=(n, 3)).astype(np.float32),
+                po=(rng.uniform(0.2, 0.8, (n, 3)) * ext).astype(np.float32),
+                pd=np.tile(np.array([[0.3, 0.9, 0.1]], np.float32), (n, 1)),
+                tg=(rng.uniform(0.0, 1.0, (n, 3)) * ext).astype(np.float32))

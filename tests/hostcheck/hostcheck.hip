@@ -32,6 +32,8 @@ EXPORT int hostcheck_trace(int mode, const float* rif, const float* sdf, const i
   int max_steps = (mode == 2) ? (int)(2.0f * h * (float)max3(res) / ds) : (int)(4.0f * h * (float)max3(res) / ds);
   long long nf = 0;
   const float zero[3] = {0, 0, 0};
+  unsigned total = 0;
+  std::vector<size_t> again;
   for (size_t i = 0; i < n; ++i) {
     const float* po = pln_o ? pln_o + 3 * i : zero; const float* pd = pln_d ? pln_d + 3 * i : zero;
     RayOut r = mode == 0 ? trace_ray<0>(V, sdf, ds, max_steps, pos + 3 * i, vel + 3 * i, po, pd)
@@ -41,6 +43,14 @@ EXPORT int hostcheck_trace(int mode, const float* rif, const float* sdf, const i
     if (failmask) failmask[i] = r.esc ? 0 : 1;
     if (steps) steps[i] = (int)r.steps;
     nf += r.act ? 1 : 0;
+    if (r.steps > total) total = r.steps;
+    if (r.again) again.push_back(i);
+  }
+  for (size_t i : again) {                               // k_trace_again
+    RayOut r = mode == 1 ? ray_full<1>(V, sdf, ds, total, pos + 3 * i, vel + 3 * i, pln_o + 3 * i, pln_d + 3 * i)
+                         : ray_full<2>(V, sdf, ds, total, pos + 3 * i, vel + 3 * i, zero, zero);
+    memcpy(xt + 3 * i, r.xt, 12); memcpy(vt + 3 * i, r.vt, 12);
+    if (failmask) failmask[i] = r.esc ? 0 : 1;
   }
   if (n_failed) *n_failed = nf;
   return 0;

@@ -124,3 +124,32 @@ def test_non_cubic_grid_bitwise(oracle):
     assert ob["steps_total"] == kb["steps_total"] and cases.rel_l2(kb["grad"], ob["grad"]) < 2e-6
     lit = oracle.trace(rif, res, pos, vel, h, ds, dtype=np.float64)
     assert np.mean(np.linalg.norm(k["xt"] - lit["xt"], axis=1) <= 2e-5) >= 0.98
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_hostcheck(oracle, seed):
+    """The per-ray code on the nasty seeded configurations of cases.fuzz_config (non-cubic grids down to 2 voxels
+    per axis, steps up to 1.7 cells, rays outside / exactly on faces, zero velocities): bit-exact forward for all
+    variants, adjoint equal up to summation order."""
+    c = cases.fuzz_config(seed)
+    res, h, ds = c["res"], c["h"], c["ds"]
+    with oracle.arith("factored"):
+        o = oracle.trace(c["rif"], res, c["pos"], c["vel"], h, ds, dtype=np.float32)
+        k = H.trace(c["rif"], res, c["pos"], c["vel"], h, ds)
+        assert np.array_equal(o["xt"], k["xt"]) and np.array_equal(o["vt"], k["vt"]) and np.array_equal(o["steps"], k["steps"])
+        ob = oracle.backtrace(c["rif"], res, o["xt"], o["vt"], c["dx"], c["dv"], h, ds, dtype=np.float32)
+        kb = H.backtrace(c["rif"], res, k["xt"], k["vt"], c["dx"], c["dv"], h, ds)
+        assert ob["steps_total"] == kb["steps_total"]
+        assert cases.rel_l2(kb["grad"], ob["grad"]) < 2e-5 or np.abs(ob["grad"]).max() < 1e-20
+        op = oracle.trace(c["rif"], res, c["pos"], c["vel"], h, ds, dtype=np.float32, mode="plane", pln_o=c["po"], pln_d=c["pd"])
+        kp = H.trace(c["rif"], res, c["pos"], c["vel"], h, ds, mode="plane", pln_o=c["po"], pln_d=c["pd"])
+        assert np.array_equal(op["xt"], kp["xt"]) and np.array_equal(op["failmask"], kp["failmask"])
+        ot = oracle.trace_target(c["rif"], res, c["pos"], c["vel"], c["tg"], h, ds, dtype=np.float32)
+        kt = H.trace_target(c["rif"], res, c["pos"], c["vel"], c["tg"], h, ds)
+        assert ot["iters"] == kt["iters"] and np.array_equal(ot["xt"], kt["xt"]) and np.array_equal(ot["dist2"], kt["dist2"])
+        os_ = oracle.trace(c["rif"], res, c["pos"], c["vel"], h, ds, dtype=np.float32, mode="sdf", sdf=c["sdf"])
+        ks = H.trace(c["rif"], res, c["pos"], c["vel"], h, ds, mode="sdf", sdf=c["sdf"])
+        assert np.array_equal(os_["xt"], ks["xt"]) and np.array_equal(os_["vt"], ks["vt"])
+        obs = oracle.backtrace(c["rif"], res, os_["xt"], os_["vt"], c["dx"], c["dv"], h, ds, dtype=np.float32, sdf=c["sdf"])
+        kbs = H.backtrace(c["rif"], res, ks["xt"], ks["vt"], c["dx"], c["dv"], h, ds, sdf=c["sdf"])
+        assert cases.rel_l2(kbs["grad"], obs["grad"]) < 2e-5 or np.abs(obs["grad"]).max() < 1e-20
