@@ -111,3 +111,44 @@ def fuzz_config(seed):
                 po=(rng.uniform(0.2, 0.8, (n, 3)) * ext).astype(np.float32),
                 pd=np.tile(np.array([[0.3, 0.9, 0.1]], np.float32), (n, 1)),
                 tg=(rng.uniform(0.0, 1.0, (n, 3)) * ext).astype(np.float32))
+
+
+def fuzz_cable_config(seed):
+    """Seeded nasty configuration for the cable (radial profile) variants: random profile length / radius /
+    cable length, rays starting inside, outside and on the axis of the cylinder, before and after its ends,
+    with arbitrary directions; steps from a fraction of a radial sample to several."""
+    rng = np.random.default_rng(2000 + seed)
+    rres = int(rng.integers(2, 200))
+    radius = float(np.float32(rng.uniform(0.1, 3.0)))
+    length = float(np.float32(rng.uniform(0.5, 8.0) * radius))
+    ds = float(np.float32(radius / max(rres - 1, 1) * rng.uniform(0.3, 3.0)))
+    prof = (1.0 + 0.5 * rng.random(rres)).astype(np.float32) if seed % 2 else \
+        np.sqrt(2.0 - np.linspace(0, 1, rres) ** 2).astype(np.float32)
+    n = 400
+    ang = rng.uniform(0, 2 * np.pi, n)
+    rad = radius * rng.uniform(0, 1.2, n)
+    pos = np.stack([radius + rad * np.cos(ang), rng.uniform(-0.1, 1.1, n) * length, radius + rad * np.sin(ang)], -1)
+    pos[rng.random(n) < 0.05, 0] = radius
+    pos[rng.random(n) < 0.05, 2] = radius
+    pos[:3] = [[radius, 0.0, radius], [radius, 0.3 * ds, radius], [2 * radius, 0.5 * length, radius]]
+    vel = rng.normal(0, 0.4, (n, 3)); vel[:, 1] = rng.choice([1.0, 1.0, 1.0, -1.0], n)
+    vel /= np.linalg.norm(vel, axis=1, keepdims=True)
+    vel[1] = [0, 1, 0]
+    tg = np.stack([radius + rng.normal(0, 0.3 * radius, n), rng.uniform(0, 1.2, n) * length,
+                   radius + rng.normal(0, 0.3 * radius, n)], -1)
+    return dict(prof=prof, radius=radius, length=length, ds=ds, pos=pos.astype(np.float32), vel=vel.astype(np.float32),
+                tg=tg.astype(np.float32), dx=rng.normal(size=(n, 3)).astype(np.float32),
+                dv=rng.normal(size=(n, 3)).astype(np.float32))
+
+
+def grads_agree(a, b, tol=2e-5):
+    """Adjoint grids equal up to summation order; non-finite entries (the adjoint recurrences grow exponentially
+    on long marches of arbitrary rays) must sit in the same places."""
+    a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    if not np.array_equal(fa, fb):
+        return False
+    if not fa.any():
+        return True
+    scale = np.abs(b[fb]).max()
+    return scale < 1e-20 or float(np.linalg.norm(a[fa] - b[fb]) / max(np.linalg.norm(b[fb]), 1e-300)) < tol

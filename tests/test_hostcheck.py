@@ -153,3 +153,24 @@ def test_fuzz_hostcheck(oracle, seed):
         obs = oracle.backtrace(c["rif"], res, os_["xt"], os_["vt"], c["dx"], c["dv"], h, ds, dtype=np.float32, sdf=c["sdf"])
         kbs = H.backtrace(c["rif"], res, ks["xt"], ks["vt"], c["dx"], c["dv"], h, ds, sdf=c["sdf"])
         assert cases.rel_l2(kbs["grad"], obs["grad"]) < 2e-5 or np.abs(obs["grad"]).max() < 1e-20
+        # the adjoint started from ARBITRARY rays (not exit states of a forward march)
+        obr = oracle.backtrace(c["rif"], res, c["pos"], c["vel"], c["dx"], c["dv"], h, ds, dtype=np.float32)
+        kbr = H.backtrace(c["rif"], res, c["pos"], c["vel"], c["dx"], c["dv"], h, ds)
+        assert obr["steps_total"] == kbr["steps_total"]
+        assert cases.grads_agree(kbr["grad"], obr["grad"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_cable_hostcheck(oracle, seed):
+    c = cases.fuzz_cable_config(seed)
+    a = (c["prof"], c["radius"], c["length"])
+    with oracle.arith("factored"):
+        o = oracle.trace_cable(*a, c["pos"], c["vel"], c["tg"], c["ds"], dtype=np.float32)
+        k = H.trace_cable(*a, c["pos"], c["vel"], c["tg"], c["ds"])
+        assert np.array_equal(o["xt"], k["xt"]) and np.array_equal(o["vt"], k["vt"]) and np.array_equal(o["dist2"], k["dist2"])
+        assert o["steps_total"] == k["steps_total"]
+        for xt, vt in ((k["xt"], k["vt"]), (c["pos"], c["vel"])):
+            ob = oracle.backtrace_cable(*a, xt, vt, c["dx"], c["dv"], c["ds"], dtype=np.float32)
+            kb = H.backtrace_cable(*a, xt, vt, c["dx"], c["dv"], c["ds"])
+            assert ob["steps_total"] == kb["steps_total"]
+            assert cases.grads_agree(kb["grad"], ob["grad"])
