@@ -107,3 +107,43 @@ def test_upres_matches_reference_run(gpu):
     (n1 ** 2).sum().backward(); o1.step()
     with pytest.raises(RuntimeError):
         optimizer.upres_scene(torch.rand(5, 5, 5), 9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_hip_sensor_fuzz(gpu, seed):
+    """Seeded random sensors: oblique planes and tangents (not axis aligned, not unit length), image sizes
+    from 3 to 97 pixels, rays that partly or entirely miss the image, scalar and per-ray e -- the fused HIP
+    forward/backward against the float64 restatement (which tests above pin to the reference's own run)."""
+    from adjointnonlinearraytracing_amd import sensor
+    from oracle import sensor_ref as S
+    rng = np.random.default_rng(300 + seed)
+    n = 5000
+    res = int(rng.integers(3, 98))
+    span = float(rng.uniform(0.3, 20.0))
+    nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+    tan = np.cross(nrm, rng.normal(size=3)); tan *= rng.uniform(0.5, 2.0) / np.linalg.norm(tan)
+    p = rng.uniform(0.3, 0.7, 3) * span + nrm * span
+    t1, t2 = S.tan_vecs(nrm, tan)
+    # ray origins behind the plane, aimed at points spread over 1.6x the image footprint
+    aim = p + (rng.uniform(-0.8, 0.8, (n, 1)) * span) * t1 / np.linalg.norm(t1) + \
+          (rng.uniform(-0.8, 0.8, (n, 1)) * span) * t2 / np.linalg.norm(t2)
+    x = aim - nrm * rng.uniform(0.2, 2.0, (n, 1)) * span + rng.normal(0, 0.1 * span, (n, 3))
+    v = aim - x + rng.normal(0, 0.05 * span, (n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    if seed % 3 == 2:
+        v = -v                                           # den < 0: foreshortening uses |v.n|
+    e = float(rng.uniform(0.5, 2.0)) if seed % 2 else rng.uniform(0.1, 2.0, n)
+    gI = rng.normal(size=(res, res))
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu, torch.float32)
+    xs, vs = f(x).requires_grad_(True), f(v).requires_grad_(True)
+    eg = f(e) if isinstance(e, np.ndarray) else e
+    img = sensor.generate_sensor((xs, vs), eg, (f(p[None]), f(nrm[None])), res, span, f(tan[None]))
+    x32, v32 = xs.detach().cpu().numpy().astype(np.float64), vs.detach().cpu().numpy().astype(np.float64)
+    e32 = e if not isinstance(e, np.ndarray) else e.astype(np.float32).astype(np.float64)
+    p32, n32, t32 = (a.astype(np.float32).astype(np.float64) for a in (p, nrm, tan))
+    ref = S.generate_sensor(x32, v32, e32, p32, n32, res, span, t32)
+    assert cases.rel_l2(img.detach().cpu().numpy(), ref) <= 2e-4
+    (img * f(gI)).sum().backward()
+    gx, gv = S.generate_sensor_backward(x32, v32, e32, p32, n32, res, span, gI.astype(np.float32).astype(np.float64), t32)
+    assert cases.rel_l2(xs.grad.cpu().numpy(), gx) <= 1e-2 and cases.rel_l2(vs.grad.cpu().numpy(), gv) <= 1e-2
