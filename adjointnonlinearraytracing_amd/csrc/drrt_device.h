@@ -93,16 +93,17 @@ DRRT_HD Cell locate(const Vol& V, float px, float py, float pz) {
   float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
   c.wx = fx - flx; c.wy = fy - fly; c.wz = fz - flz;
   int ix = f2i_sat(flx), iy = f2i_sat(fly), iz = f2i_sat(flz);
-  c.interior = ((unsigned)(ix - 1) < V.lx) & ((unsigned)(iy - 1) < V.ly) & ((unsigned)(iz - 1) < V.lz);
+  c.interior = (((unsigned)ix - 1u) < V.lx) & (((unsigned)iy - 1u) < V.ly) & (((unsigned)iz - 1u) < V.lz);   // wraps, no UB
   if (c.interior) {                      // fast path: the clamps below are no-ops here
     c.base = mad24(iz, V.sz, mad24(iy, V.sy, ix));
     c.ix = ix; c.iy = iy; c.iz = iz;
     c.ox = 1; c.oy = V.sy; c.oz = V.sz;
     return c;
   }
-  int x0 = clampi(ix, 0, V.W - 1), x1 = clampi(ix + 1, 0, V.W - 1);
-  int y0 = clampi(iy, 0, V.H - 1), y1 = clampi(iy + 1, 0, V.H - 1);
-  int z0 = clampi(iz, 0, V.D - 1), z1 = clampi(iz + 1, 0, V.D - 1);
+  // clamp(i + 1, 0, res - 1) written so that a saturated index (huge or non-finite coordinate) cannot overflow
+  int x0 = clampi(ix, 0, V.W - 1), x1 = clampi(ix, -1, V.W - 2) + 1;
+  int y0 = clampi(iy, 0, V.H - 1), y1 = clampi(iy, -1, V.H - 2) + 1;
+  int z0 = clampi(iz, 0, V.D - 1), z1 = clampi(iz, -1, V.D - 2) + 1;
   c.base = mad24(z0, V.sz, mad24(y0, V.sy, x0));
   c.ix = x0; c.iy = y0; c.iz = z0;
   c.ox = x1 - x0; c.oy = (y1 != y0) ? V.sy : 0; c.oz = (z1 != z0) ? V.sz : 0;

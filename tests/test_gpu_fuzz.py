@@ -100,3 +100,54 @@ def test_fuzz_cable_against_oracle(gpu, oracle, seed):
             ob = oracle.backtrace_cable(*a, xn, vn, c["dx"], c["dv"], c["ds"], dtype=np.float32)
             assert sa["ray_steps"] == ob["steps_total"]
             assert cases.grads_agree(g.cpu().numpy(), ob["grad"], tol=1e-4)
+
+
+@pytest.mark.parametrize("sort", [True, False])
+def test_nonfinite_rays_do_not_disturb_the_others(gpu, sort):
+    """NaN / Inf / huge / denormal components planted in some rays (and adjoint seeds): every call returns and the
+    untouched rays' forward results are bit-identical to a clean run.  Bad rays contaminate the gradient voxels
+    they touch, so for the adjoint only completion is asserted.  (The host build of the same per-ray code runs
+    these inputs under ASan/UBSan in tests/test_hostcheck.py.)"""
+    from adjointnonlinearraytracing_amd import drrt
+    drrt.options.check_failed = False
+    drrt.options.sort_rays = sort
+    try:
+        rng = np.random.default_rng(77)
+        bad_vals = np.array([np.nan, np.inf, -np.inf, 3e38, -3e38, 1e30, -1e30, 1e-40], np.float32)
+        T = drrt.TracerC()
+        for seed in (1, 2, 5):
+            c = cases.fuzz_config(seed)
+            res, h, ds = c["res"], c["h"], c["ds"]
+            n = len(c["pos"])
+            pos, vel, dx = c["pos"].copy(), c["vel"].copy(), c["dx"].copy()
+            bad = rng.choice(n, 80, replace=False)
+            pos[bad[:30], rng.integers(0, 3, 30)] = rng.choice(bad_vals, 30)
+            vel[bad[30:60], rng.integers(0, 3, 30)] = rng.choice(bad_vals, 30)
+            dx[bad[60:], rng.integers(0, 3, 20)] = rng.choice(bad_vals, 20)
+            good = torch.from_numpy(np.setdiff1d(np.arange(n), bad[:60])).to(gpu)
+            R, S = _t(c["rif"], gpu).reshape(-1), _t(c["sdf"], gpu).reshape(-1)
+            clean = T.trace(R, res, _t(c["pos"], gpu), _t(c["vel"], gpu), h, ds)
+            xt, vt = T.trace(R, res, _t(pos, gpu), _t(vel, gpu), h, ds)
+            assert torch.equal(xt[good], clean[0][good]) and torch.equal(vt[good], clean[1][good])
+            xp, vp, fm = T.trace_pln(R, res, _t(pos, gpu), _t(vel, gpu), _t(c["po"], gpu), _t(c["pd"], gpu), h, ds)
+            xs, vs = T.trace_sdf(R, S, res, _t(pos, gpu), _t(vel, gpu), h, ds)
+            xg, vg, d2 = T.trace_target(R, res, _t(pos, gpu), _t(vel, gpu), _t(c["tg"], gpu), h, ds)
+            g = T.backtrace(R, res, xt, vt, _t(dx, gpu), _t(c["dv"], gpu), h, ds)
+            g2 = T.backtrace(R, res, _t(pos, gpu), _t(vel, gpu), _t(dx, gpu), _t(c["dv"], gpu), h, ds)
+            gs = T.backtrace_sdf(R, S, res, xs, vs, _t(dx, gpu), _t(c["dv"], gpu), h, ds)
+            torch.cuda.synchronize()
+            assert g.shape == g2.shape == gs.shape == R.shape
+        for seed in (0, 3):
+            c = cases.fuzz_cable_config(seed)
+            n = len(c["pos"])
+            pos, vel = c["pos"].copy(), c["vel"].copy()
+            bad = rng.choice(n, 40, replace=False)
+            pos[bad[:20], rng.integers(0, 3, 20)] = rng.choice(bad_vals, 20)
+            vel[bad[20:], rng.integers(0, 3, 20)] = rng.choice(bad_vals, 20)
+            prof = _t(c["prof"], gpu)
+            xt, vt, d2 = T.trace_cable(prof, c["radius"], c["length"], _t(pos, gpu), _t(vel, gpu), _t(c["tg"], gpu), c["ds"])
+            g = T.backtrace_cable(prof, c["radius"], c["length"], xt, vt, _t(c["dx"], gpu), _t(c["dv"], gpu), c["ds"])
+            torch.cuda.synchronize()
+            assert g.shape == prof.shape
+    finally:
+        drrt.options.sort_rays = True
