@@ -59,7 +59,7 @@ SIGNATURES = {
     "drrt_sensor_splat_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "drrt_upres_volume_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "drrt_gen_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "drrt_gen_plane_rays_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "drrt_gen_rays_f32": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drrt_last_order": (_vp, [_vp]),
     "drrt_set_order_hint": (None, [_vp, _sz]),
     "drrt_profile_begin": (_i, [_i]),

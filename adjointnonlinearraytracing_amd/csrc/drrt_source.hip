@@ -4,6 +4,8 @@
 // Reference semantics (all torch on the host, /root/reference/core/source.py):
 //   :54-69    plane_source3_rand     jittered (or independent) points on the y = 0 plane, spp samples
 //                                    per pixel, candidate order (s, i, j)
+//   :72-104   point_source3_rand     rays from the point (0, -w/2, 0) through jittered pixel centres of the plane
+//                                    y = w/2 (kind 1; :360-365 rand_ptrays_in_sphere concatenates the views)
 //   :275-293  rotate_pts_to_source   optional disc mask r < width/2 (order-preserving compaction),
 //                                    x = p R^T + width/2 - width v/2, v = R e_y, t = R e_z,
 //                                    sensor plane (point, normal, tangent) per ray
@@ -41,6 +43,7 @@ struct GenArgs {
   int has_ic;
   int n_views, spp, p0, p1;
   int circle, independent;
+  int kind;                // 0 = plane source (source.py:54-69), 1 = point source (:72-104)
   float width, half_width, plane_scale, half_span;
   unsigned cand_per_view, blocks_per_view;
   float* x; float* v; float* planes;
@@ -56,7 +59,13 @@ __device__ __forceinline__ bool gen_point(const GenArgs& a, int view, unsigned c
   const float* uv = a.u + (size_t)view * 2u * a.spp * pp;
   const float o0 = uv[(size_t)s * pp + rem] * a.width;                       // source.py:56
   const float o1 = uv[(size_t)(a.spp + s) * pp + rem] * a.width;
-  if (a.independent) {                                                       // :61-63
+  if (a.kind == 1) {                                                         // point source, :73-83
+    // jitter is (u - 0.5) in ABSOLUTE units around the pixel centres, as written in the reference
+    const float r0 = a.width * (((float)i + 0.5f) / (float)a.p0 - 0.5f);
+    const float r1 = a.width * (((float)j + 0.5f) / (float)a.p1 - 0.5f);
+    px = r0 + (uv[(size_t)s * pp + rem] - 0.5f);
+    pz = r1 + (uv[(size_t)(a.spp + s) * pp + rem] - 0.5f);
+  } else if (a.independent) {                                                // :61-63
     px = o0 - a.half_width;
     pz = o1 - a.half_width;
   } else {                                                                   // :57-58, 65-68
@@ -66,7 +75,7 @@ __device__ __forceinline__ bool gen_point(const GenArgs& a, int view, unsigned c
     pz = r1 + o1 / (float)a.p1;
   }
   if (!a.circle) return true;
-  return sqrtf(px * px + pz * pz) < a.half_width;                            // :278-280
+  return sqrtf(px * px + pz * pz) < a.half_width;                            // :278-280 / :81-83
 }
 
 __device__ __forceinline__ void mat3(const float* R, const float p[3], float out[3]) {
@@ -146,7 +155,8 @@ __global__ void __launch_bounds__(GEN_BLOCK) k_gen_write(GenArgs a) {
   for (int k = 0; k < 3; ++k) {
     vdir[k] = R[3 * k + 1];
     tdir[k] = R[3 * k + 2];
-    pl[k] = a.plane_scale * vdir[k] + a.half_width;
+    pl[k] = (a.kind == 1) ? (a.plane_scale * vdir[k]) / 2.f + a.half_width       // :102
+                          : a.plane_scale * vdir[k] + a.half_width;            // :290
   }
   float vv[3] = {vdir[0], vdir[1], vdir[2]}, tt[3] = {tdir[0], tdir[1], tdir[2]}, pp[3] = {pl[0], pl[1], pl[2]};
   if (a.has_ic) {                                                            // source.py:557-561
@@ -166,13 +176,26 @@ __global__ void __launch_bounds__(GEN_BLOCK) k_gen_write(GenArgs a) {
     unsigned tot;
     const unsigned rank = block_rank(keep, tot, wave_tot);
     if (keep) {
-      const float p[3] = {px, 0.f, pz};
-      float x[3];
-      mat3(R, p, x);                                                         // :284
+      float x[3], vray[3] = {vv[0], vv[1], vv[2]};
+      if (a.kind == 1) {
+        // direction (px, width, pz) normalised (:85-89), rotated (:96); origin R (0, -w/2, 0) + w/2 (:94-95)
+        const float nrm = sqrtf((px * px + a.width * a.width) + pz * pz);
+        const float d[3] = {px / nrm, a.width / nrm, pz / nrm};
+        float vr[3];
+        mat3(R, d, vr);
+        const float o[3] = {0.f, -a.half_width, 0.f};
+        mat3(R, o, x);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        x[k] += a.half_width;
-        x[k] -= (a.width * vdir[k]) / 2.f;                                   // :287
+        for (int k = 0; k < 3; ++k) { x[k] += a.half_width; vray[k] = vr[k]; }
+        if (a.has_ic) mat3(a.ic_rot, vr, vray);
+      } else {
+        const float p[3] = {px, 0.f, pz};
+        mat3(R, p, x);                                                       // :284
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          x[k] += a.half_width;
+          x[k] -= (a.width * vdir[k]) / 2.f;                                 // :287
+        }
       }
       if (a.has_ic) {
         const float q[3] = {x[0] - a.half_span, x[1] - a.half_span, x[2] - a.half_span};
@@ -184,7 +207,7 @@ __global__ void __launch_bounds__(GEN_BLOCK) k_gen_write(GenArgs a) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         a.x[3 * o + k] = x[k];
-        a.v[3 * o + k] = vv[k];
+        a.v[3 * o + k] = vray[k];
         a.planes[9 * o + k] = pp[k];
         a.planes[9 * o + 3 + k] = vv[k];
         a.planes[9 * o + 6 + k] = tt[k];
@@ -203,13 +226,14 @@ extern "C" size_t drrt_gen_workspace_bytes(int n_views, int spp, int p0, int p1)
   return ((size_t)n_views * bpv + 1) * sizeof(int);
 }
 
-extern "C" int drrt_gen_plane_rays_f32(const float* u, const float* view_rot, int n_views, int spp, int p0, int p1,
-                                       double width, double sensor_dist, int circle, int independent,
-                                       const float* ic_rot_host, double span, float* x, float* v, float* planes,
-                                       int* view_counts, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int drrt_gen_rays_f32(int kind, const float* u, const float* view_rot, int n_views, int spp, int p0, int p1,
+                                 double width, double sensor_dist, int circle, int independent,
+                                 const float* ic_rot_host, double span, float* x, float* v, float* planes,
+                                 int* view_counts, void* workspace, size_t workspace_bytes, void* stream) {
   using namespace drrt;
   if (!u || !view_rot || !x || !v || !planes || !view_counts || !workspace)
     return sensor_fail(DRRT_ERR_ARG, "null pointer");
+  if (kind != 0 && kind != 1) return sensor_fail(DRRT_ERR_ARG, "source kind must be 0 (plane) or 1 (point)");
   if (n_views < 1 || n_views > 65535 || spp < 1 || p0 < 1 || p1 < 1) return sensor_fail(DRRT_ERR_ARG, "bad view / pixel counts");
   const unsigned long long cand = (unsigned long long)spp * p0 * p1;
   if (cand * (unsigned long long)n_views >= (1ull << 31)) return sensor_fail(DRRT_ERR_ARG, "too many candidate rays (>= 2^31)");
@@ -223,7 +247,9 @@ extern "C" int drrt_gen_plane_rays_f32(const float* u, const float* view_rot, in
   a.circle = circle != 0; a.independent = independent != 0;
   // python scalars of the reference are doubles, rounded to fp32 when they meet an fp32 tensor
   a.width = (float)width; a.half_width = (float)(width / 2.0);
-  a.plane_scale = (float)(sensor_dist + width / 2.0);                         // source.py:290
+  a.kind = kind;
+  a.plane_scale = kind == 1 ? (float)(sensor_dist * width)                    // source.py:102
+                            : (float)(sensor_dist + width / 2.0);             // source.py:290
   a.half_span = (float)(span / 2.0);
   a.cand_per_view = (unsigned)cand;
   a.blocks_per_view = (unsigned)((cand + GEN_CHUNK - 1) / GEN_CHUNK);

@@ -1,7 +1,8 @@
 """Counterpart of the ray generators of the reference's ``core/source.py`` that feed the march in the
 3-D scripts: ``plane_source3_rand`` (``:54-69``, with ``rotate_pts_to_source`` ``:275-293`` and
-``rotate_ray3`` ``:303-312``), ``rand_rays_in_sphere`` (``:352-357``), ``rand_rays_cube``
-(``:398-412``, plane source) and ``random_rotate_ic`` (``:555-563``).
+``rotate_ray3`` ``:303-312``), ``point_source3_rand`` (``:72-104``), ``rand_rays_in_sphere`` (``:352-357``),
+``rand_ptrays_in_sphere`` (``:360-365``), ``rand_rays_cube`` (``:398-412``, plane source) and
+``random_rotate_ic`` (``:555-563``).
 
 Same names, argument order and return structure as the reference; the rays are produced ON the
 device by ``csrc/drrt_source.hip`` (all views of a call in three launches, order-preserving disc
@@ -14,8 +15,8 @@ compaction included) instead of on the host followed by an upload.  Keyword-only
 * ``rotmat``  -- a 3x3 matrix: fuses ``random_rotate_ic`` into the generation (saves a second pass
   over the 15 floats per ray).
 
-The point / cone / area sources (``:72-272``) are not on the accelerated path: ``rand_rays_cube``
-with ``src_type != 'plane'`` raises ``NotImplementedError``.
+The deterministic point source and the cone / area sources (``:29-51``, ``:107-272``) are not on the
+accelerated path: ``rand_rays_cube`` with ``src_type != 'plane'`` raises ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -49,8 +50,8 @@ def rotate_ray3(x, angle, vert=False):
     return torch.matmul(x, R.T)
 
 
-def _generate(view_mats, pixels, spp, width, circle, sensor_dist, independent, offset, device, rotmat, span):
-    """All views of one call through drrt_gen_plane_rays_f32; returns (x, v, planes), nrays."""
+def _generate(view_mats, pixels, spp, width, circle, sensor_dist, independent, offset, device, rotmat, span, kind=0):
+    """All views of one call through drrt_gen_rays_f32; returns (x, v, planes), nrays."""
     dev = torch.device("cuda" if device is None else device)
     if dev.type != "cuda":
         raise RuntimeError("ray generation runs on the cuda (ROCm) device only (no CPU path)")
@@ -74,8 +75,8 @@ def _generate(view_mats, pixels, spp, width, circle, sensor_dist, independent, o
         else:
             m = rotmat.detach().cpu().numpy() if isinstance(rotmat, torch.Tensor) else np.asarray(rotmat)
             ic = (C.c_float * 9)(*np.asarray(m, dtype=np.float64).astype(np.float32).reshape(9).tolist())
-        _lib.check(lib.drrt_gen_plane_rays_f32(
-            C.c_void_p(u.data_ptr()), C.c_void_p(rots.data_ptr()), nv, spp, p0, p1, float(width), float(sensor_dist),
+        _lib.check(lib.drrt_gen_rays_f32(
+            int(kind), C.c_void_p(u.data_ptr()), C.c_void_p(rots.data_ptr()), nv, spp, p0, p1, float(width), float(sensor_dist),
             int(bool(circle)), int(bool(independent)), ic, float(span if span is not None else width),
             C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(planes.data_ptr()),
             C.c_void_p(counts.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
@@ -100,6 +101,23 @@ def rand_rays_in_sphere(nviews, im_res, spp, width, angle_span=360, circle=False
     angles = torch.linspace(0, angle_span, nviews + 1)
     mats = [_view_matrix(angles[i], xaxis) for i in range(nviews)]
     return _generate(mats, im_res, spp, width, circle, sensor_dist, indep, offset, device, rotmat, span)
+
+
+def point_source3_rand(angle, pixels, spp, width, circle=False, xaxis=False, sensor_dist=1.0,
+                       *, offset=None, device=None, rotmat=None, span=None):
+    """core/source.py:72-104 -> (x, v, planes): rays from the point (0, -width/2, 0) (rotated) through jittered
+    pixel centres."""
+    iv, _ = _generate([_view_matrix(angle, xaxis)], pixels, spp, width, circle, sensor_dist, False,
+                      None if offset is None else offset[None], device, rotmat, span, kind=1)
+    return iv
+
+
+def rand_ptrays_in_sphere(nviews, im_res, spp, width, angle_span=360, circle=False, xaxis=False, sensor_dist=0.0,
+                          *, offset=None, device=None, rotmat=None, span=None):
+    """core/source.py:360-365 -> ((x, v, planes), nrays)."""
+    angles = torch.linspace(0, angle_span, nviews + 1)
+    mats = [_view_matrix(angles[i], xaxis) for i in range(nviews)]
+    return _generate(mats, im_res, spp, width, circle, sensor_dist, False, offset, device, rotmat, span, kind=1)
 
 
 def rand_rays_cube(im_res, spp, width, circle=False, src_type='plane', cone_ang=90,

@@ -223,25 +223,28 @@ DRRT_API int drrt_upres_volume_f32(const float* src, const int src_shape[3], flo
                           void* stream);
 
 /* ---- ray generation (SURVEY.md 8.8 "next" row 2) ---------------------------------------------------
- * core/source.py:54-69 plane_source3_rand + :275-293 rotate_pts_to_source for n_views views in one
- * call (what :352-357 rand_rays_in_sphere and :398-412 rand_rays_cube concatenate), optionally followed
- * by :555-563 random_rotate_ic.  All pointers are DEVICE pointers except ic_rot.
+ * kind 0: core/source.py:54-69 plane_source3_rand + :275-293 rotate_pts_to_source;
+ * kind 1: :72-104 point_source3_rand -- for n_views views in one call (what :352-357 rand_rays_in_sphere,
+ * :360-365 rand_ptrays_in_sphere and :398-412 rand_rays_cube concatenate), optionally followed by
+ * :555-563 random_rotate_ic.  All pointers are DEVICE pointers except ic_rot.
  *   u          fp32[n_views][2*spp][p0][p1] uniforms in [0,1) (the reference's torch.rand draws)
  *   view_rot   fp32[n_views][9] row-major rotate_ray3 matrix of each view (:303-312)
  *   width, sensor_dist, span   python scalars of the reference (doubles, rounded to fp32 where the
  *              reference's tensors are fp32)
- *   circle     keep only points with r < width/2 (order-preserving compaction, :277-280)
- *   independent  :60-63 instead of the jittered pixel grid
+ *   circle     keep only points with r < width/2 (order-preserving compaction, :277-280 / :81-92)
+ *   independent  kind 0 only: :60-63 instead of the jittered pixel grid
  *   ic_rot     HOST pointer to 9 floats (row-major M) or NULL: x' = M (x - span/2) + span/2 etc.
  *   x, v       fp32[cap][3], planes fp32[cap][3][3] with cap = n_views*spp*p0*p1; kept rays are
  *              written densely in the reference's order (view, sample, pixel row, pixel column)
  *   view_counts  int32[n_views+1]: exclusive prefix of kept rays per view, [n_views] = total
  *   workspace  drrt_gen_workspace_bytes(...) bytes of device scratch                                */
+#define DRRT_SOURCE_PLANE 0
+#define DRRT_SOURCE_POINT 1
 DRRT_API size_t drrt_gen_workspace_bytes(int n_views, int spp, int p0, int p1);
-DRRT_API int drrt_gen_plane_rays_f32(const float* u, const float* view_rot, int n_views, int spp, int p0, int p1,
-                            double width, double sensor_dist, int circle, int independent,
-                            const float* ic_rot, double span, float* x, float* v, float* planes,
-                            int* view_counts, void* workspace, size_t workspace_bytes, void* stream);
+DRRT_API int drrt_gen_rays_f32(int kind, const float* u, const float* view_rot, int n_views, int spp, int p0, int p1,
+                      double width, double sensor_dist, int circle, int independent,
+                      const float* ic_rot, double span, float* x, float* v, float* planes,
+                      int* view_counts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- profiling aid (bench.py; no counterpart in the reference) --------------------------------
  * After drrt_profile_begin(capacity) every march call records a HIP event pair on its stream

@@ -62,9 +62,37 @@ def plane_view(u, R, pixels, spp, width, circle=False, sensor_dist=1.0, independ
     return x.astype(F), v, planes
 
 
-def views(u, mats, pixels, spp, width, circle=False, sensor_dist=1.0, independent=False):
-    """Concatenation over views (:352-357 / :398-412): ((x, v, planes), nrays)."""
-    parts = [plane_view(u[i], mats[i], pixels, spp, width, circle, sensor_dist, independent) for i in range(len(mats))]
+def point_view(u, R, pixels, spp, width, circle=False, sensor_dist=1.0):
+    """One view of point_source3_rand (:72-104): u (2*spp, P0, P1) uniforms -> x, v, planes (float32)."""
+    p0, p1 = int(pixels[0]), int(pixels[1])
+    u = np.asarray(u, F).reshape(2 * spp, p0, p1)
+    w, hw = F(width), F(width / 2)
+    off = u - F(0.5)                                                       # :73
+    r0 = w * ((np.arange(p0).astype(F) + F(0.5)) / F(p0) - F(0.5))         # :75
+    r1 = w * ((np.arange(p1).astype(F) + F(0.5)) / F(p1) - F(0.5))
+    px = (r0[None, :, None] + off[:spp]).reshape(-1)
+    pz = (r1[None, None, :] + off[spp:]).reshape(-1)
+    if circle:                                                             # :81-83, 91-92
+        keep = np.sqrt(px * px + pz * pz) < hw
+        px, pz = px[keep], pz[keep]
+    n = len(px)
+    nrm = np.sqrt((px * px + w * w) + pz * pz)                             # :88-89
+    vel = np.stack([px / nrm, np.full(n, w, F) / nrm, pz / nrm], axis=-1).astype(F)
+    vdir, tdir = R[:, 1].copy(), R[:, 2].copy()
+    pos = np.tile(np.array([[0.0, -hw, 0.0]], F), (n, 1))
+    x = _rot(pos, R) + hw                                                  # :94-95
+    v = _rot(vel, R)                                                       # :96
+    plane_x = (F(sensor_dist * width) * vdir) / F(2) + hw                  # :102
+    planes = np.broadcast_to(np.stack([plane_x, vdir, tdir])[None], (n, 3, 3)).astype(F).copy()
+    return x.astype(F), v.astype(F), planes
+
+
+def views(u, mats, pixels, spp, width, circle=False, sensor_dist=1.0, independent=False, kind="plane"):
+    """Concatenation over views (:352-357 / :360-365 / :398-412): ((x, v, planes), nrays)."""
+    if kind == "point":
+        parts = [point_view(u[i], mats[i], pixels, spp, width, circle, sensor_dist) for i in range(len(mats))]
+    else:
+        parts = [plane_view(u[i], mats[i], pixels, spp, width, circle, sensor_dist, independent) for i in range(len(mats))]
     nrays = [len(p[0]) for p in parts]
     return tuple(np.concatenate(q) for q in zip(*parts)), nrays
 

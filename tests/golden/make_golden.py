@@ -214,6 +214,17 @@ def source_rays():
     (x, v, pl), nr = ref_source.rand_rays_in_sphere(3, pix, spp, 0.3, angle_span=360, circle=True, xaxis=True,
                                                     sensor_dist=1.0, indep=True)
     out.update(ind_x=x.numpy(), ind_v=v.numpy(), ind_planes=pl.numpy(), ind_nrays=np.array(nr))
+    # point sources (fuel_injection_opt.py:51 / image_opt.py:49): 4 views, no mask; and 3 views with the disc mask
+    out["pt_u"] = draws(14, 4).numpy()
+    torch.manual_seed(14)
+    (x, v, pl), nr = ref_source.rand_ptrays_in_sphere(4, pix, spp, width, angle_span=360, circle=False, xaxis=False,
+                                                      sensor_dist=0.5)
+    out.update(pt_x=x.numpy(), pt_v=v.numpy(), pt_planes=pl.numpy(), pt_nrays=np.array(nr))
+    out["ptc_u"] = draws(15, 3).numpy()
+    torch.manual_seed(15)
+    (x, v, pl), nr = ref_source.rand_ptrays_in_sphere(3, pix, spp, 3.0, angle_span=270, circle=True, xaxis=True,
+                                                      sensor_dist=0.0)
+    out.update(ptc_x=x.numpy(), ptc_v=v.numpy(), ptc_planes=pl.numpy(), ptc_nrays=np.array(nr))
     save("source_rays.npz", **out)
 
 

@@ -60,6 +60,17 @@ def test_restatement_matches_reference_sphere_and_independent(gold, SR):
     _close(x, gold["ind_x"], ulps(0.3)); _close(v, gold["ind_v"], 0.0); _close(pl, gold["ind_planes"], ulps(1.3))
 
 
+def test_restatement_matches_reference_point_sources(gold, SR):
+    (x, v, pl), nr = SR.views(gold["pt_u"], SR.sphere_mats(4, 360), PIX, SPP, 20.0, circle=False, sensor_dist=0.5,
+                              kind="point")
+    assert nr == gold["pt_nrays"].tolist() == [240] * 4
+    _close(x, gold["pt_x"], ulps(20.0)); _close(v, gold["pt_v"], ulps(1.0)); _close(pl, gold["pt_planes"], ulps(20.0))
+    (x, v, pl), nr = SR.views(gold["ptc_u"], SR.sphere_mats(3, 270, xaxis=True), PIX, SPP, 3.0, circle=True,
+                              sensor_dist=0.0, kind="point")
+    assert nr == gold["ptc_nrays"].tolist()
+    _close(x, gold["ptc_x"], ulps(3.0)); _close(v, gold["ptc_v"], ulps(1.0)); _close(pl, gold["ptc_planes"], ulps(3.0))
+
+
 # ------------------------------------------------------------------------------------ GPU tier
 @pytest.fixture(scope="module")
 def S():
@@ -104,6 +115,32 @@ def test_hip_sphere_and_independent_match_reference(gold, S):
     x1, v1, pl1 = S.plane_source3_rand(torch.tensor(0.0), PIX, SPP, 20.0, sensor_dist=0.7,
                                        offset=torch.from_numpy(gold["sph_u"][0]))
     _close(_np(x1), gold["sph_x"][:240], ulps(20.0))
+
+
+@pytest.mark.gpu
+def test_hip_point_sources_match_reference(gold, S, SR):
+    import torch
+    (x, v, pl), nr = S.rand_ptrays_in_sphere(4, PIX, SPP, 20.0, sensor_dist=0.5, offset=torch.from_numpy(gold["pt_u"]))
+    assert nr == [240] * 4
+    _close(_np(x), gold["pt_x"], ulps(20.0)); _close(_np(v), gold["pt_v"], ulps(1.0))
+    _close(_np(pl), gold["pt_planes"], ulps(20.0))
+    (x, v, pl), nr = S.rand_ptrays_in_sphere(3, PIX, SPP, 3.0, angle_span=270, circle=True, xaxis=True,
+                                             sensor_dist=0.0, offset=torch.from_numpy(gold["ptc_u"]))
+    assert nr == gold["ptc_nrays"].tolist()
+    _close(_np(x), gold["ptc_x"], ulps(3.0)); _close(_np(v), gold["ptc_v"], ulps(1.0))
+    _close(_np(pl), gold["ptc_planes"], ulps(3.0))
+    x1, v1, pl1 = S.point_source3_rand(torch.tensor(0.0), PIX, SPP, 20.0, sensor_dist=0.5,
+                                       offset=torch.from_numpy(gold["pt_u"][0]))
+    _close(_np(v1), gold["pt_v"][:240], ulps(1.0))
+    # at size, against the restatement (bit-exact: same fp32 operation order), with a fused random_rotate_ic
+    rng = np.random.default_rng(8)
+    u = rng.random((5, 6, 200, 173), dtype=np.float32)
+    (x, v, pl), nr = S.rand_ptrays_in_sphere(5, (200, 173), 3, 7.0, angle_span=300, circle=True, sensor_dist=0.3,
+                                             offset=torch.from_numpy(u))
+    (xo, vo, plo), nro = SR.views(u, SR.sphere_mats(5, 300), (200, 173), 3, 7.0, circle=True, sensor_dist=0.3,
+                                  kind="point")
+    assert nr == nro
+    assert np.array_equal(_np(x), xo) and np.array_equal(_np(v), vo) and np.array_equal(_np(pl), plo)
 
 
 @pytest.mark.gpu
