@@ -539,7 +539,9 @@ __device__ __forceinline__ bool shift_emit4(const WinCtx& W, int cx, int cy, int
   return inw;
 }
 
-template <int MODE>
+// ABL = true compiles the development ablations and debug counters in (DRRT_FLAG_DEBUG_COUNTERS or ablation
+// bits set); the product instantiation has neither in its loop.
+template <int MODE, bool ABL = false>
 __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
   __shared__ win_t s_win[kWavesPerBlock][kWinFloats];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
@@ -562,7 +564,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
     }
   }
   WinCtx W;
-  W.win = win; W.grad = a.grad; W.sy = V.sy; W.sz = V.sz; W.experiment = a.experiment;
+  W.win = win; W.grad = a.grad; W.sy = V.sy; W.sz = V.sz; W.experiment = ABL ? a.experiment : 0;
   // window origin (wave-uniform).  Start far away: nothing is "in the window" before the first anchor.
   W.wox = W.woy = W.woz = -(1 << 28);
   bool acc_valid = false;
@@ -572,7 +574,8 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
   int cooldown = 0;
   unsigned steps = 0;
   unsigned n_flush = 0, n_lds = 0, n_glb = 0;
-  const int experiment = a.experiment;
+  const int experiment = ABL ? a.experiment : 0;
+  unsigned long long* const dbg = ABL ? a.dbg : nullptr;
 
   for (int it = 0; it < a.max_steps; ++it) {
     if (!__any(s.active | acc_valid)) break;                                  // wave-uniform exit
@@ -619,7 +622,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
     }
     bool used_lds = false;
     if (contrib) {
-      if (a.dbg) { if (inw) ++n_lds; else ++n_glb; }
+      if (ABL && dbg) { if (inw) ++n_lds; else ++n_glb; }
       if (!regular) {
         // clamped boundary cell: taps coincide; bypass accumulators and window
         if (acc_valid) { used_lds |= emit8(W, acx, acy, acz, abase, a000, a100, a010, a110, a001, a101, a011, a111); acc_valid = false; }
@@ -659,12 +662,12 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
   if (acc_valid && experiment != 1) { if (emit8(W, acx, acy, acz, abase, a000, a100, a010, a110, a001, a101, a011, a111)) dirty = true; }
   dirty = __ballot(dirty) != 0ull;
   if (dirty) { win_flush(win, W.wox, W.woy, W.woz, a.grad, V, lane, experiment == 2); ++n_flush; }
-  if (a.dbg) {
+  if (ABL && dbg) {
     unsigned f = lane == 0 ? n_flush : 0u;
     unsigned l = wave_sum_u32(n_lds), g = wave_sum_u32(n_glb);
     if (lane == 0) {
-      atomicAdd(&a.dbg[0], (unsigned long long)f); atomicAdd(&a.dbg[1], (unsigned long long)l);
-      atomicAdd(&a.dbg[2], (unsigned long long)g);
+      atomicAdd(&dbg[0], (unsigned long long)f); atomicAdd(&dbg[1], (unsigned long long)l);
+      atomicAdd(&dbg[2], (unsigned long long)g);
     }
   }
   block_stats(a.stats, steps, 0u);
@@ -1096,8 +1099,10 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
     ProfScope prof(DRRT_PROF_BACKTRACE, s);
     if (flags & DRRT_FLAG_DIRECT_ATOMICS)
       hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    else if (a.experiment != 0 || a.dbg != nullptr)
+      hipLaunchKernelGGL((k_backtrace_win<MODE, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
     else
-      hipLaunchKernelGGL(k_backtrace_win<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_backtrace_win<MODE, false>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
   }
   LAUNCH_CHECK("k_backtrace");
   return DRRT_OK;
