@@ -79,6 +79,16 @@ extern "C" {
                                        the LDS window, [2] ray-steps that fell back to global atomics.
                                        Bits 8..15 of `flags` select development ablations (0 = product) */
 
+/* Limits (violations are refused with DRRT_ERR_ARG and a message, never truncated silently):
+ *   grid      fewer than 2^29 voxels (2 GiB of fp32), each extent and res[0]*res[1] below 2^24
+ *             (e.g. up to 812^3, or 4095 x 4095 x 32); res[0], res[1] >= 2 as in the reference (src/volume.cpp:123)
+ *   rays      n < 2^32 per call
+ *   h, ds     positive and finite
+ * Non-finite ray components are tolerated: such rays march until max_steps and do not affect other rays'
+ * forward results (their adjoint contributions are non-finite, as in any IEEE implementation).
+ * Thread-safety: the visit-order hand-over (drrt_last_order / drrt_set_order_hint) and the profiling aid are
+ * process-global; use the library from one host thread per process (one process per GPU).            */
+
 typedef struct drrt_stats {
   unsigned long long ray_steps;  /* sum over rays of march iterations executed while the ray was live */
   unsigned long long n_failed;   /* rays still live after max_steps                                  */
