@@ -226,3 +226,42 @@ def test_large_noncubic_grid_512x384x320(gpu, oracle, D):
     finally:
         D.options.direct_atomics = False
     assert cases.rel_l2(g.cpu().numpy(), g2.cpu().numpy()) <= 2e-5
+
+
+def test_grid_near_the_size_limit(gpu, oracle, D):
+    """Maximum sizes: a 1024 x 1024 x 500 grid (5.2e8 voxels, just under the 2^29 limit; flat byte offsets up to
+    2.1e9, just under 2^31) with rays through its far-z end -- forward bit-exact, adjoint equal on the touched
+    voxels and zero elsewhere; one voxel more than the limit is refused."""
+    W, H, Dz = 1024, 1024, 500
+    h = 1.0 / 1023; ds = h / 2
+    rng = np.random.default_rng(12)
+    rif = np.empty((Dz, H, W), np.float32)
+    base = (1.0 + 2e-4 * rng.random((8, H, W), dtype=np.float32)).astype(np.float32)   # |grad n| ~ 0.2
+    for z0 in range(0, Dz, 8):                                    # cheap to build, still varies along z
+        rif[z0:z0 + 8] = base[: min(8, Dz - z0)] + np.float32(1e-6 * z0)
+    res = (W, H, Dz)
+    n = 3000
+    pos = np.stack([rng.uniform(0.1, 0.9, n), np.zeros(n), (Dz - 1) * h * rng.uniform(0.97, 0.999, n)], -1).astype(np.float32)
+    vel = rng.normal(0, 0.02, (n, 3)).astype(np.float32); vel[:, 1] = 1.0
+    vel /= np.linalg.norm(vel, axis=1, keepdims=True)
+    T = D.TracerC()
+    rif_d = _t(rif.reshape(-1), gpu)
+    xt, vt = T.trace(rif_d, res, _t(pos, gpu), _t(vel, gpu), h, ds)
+    order = D.last_order
+    with oracle.arith("factored"):
+        o = oracle.trace(rif, res, pos, vel, h, ds, dtype=np.float32)
+    assert np.array_equal(xt.cpu().numpy(), o["xt"]) and np.array_equal(vt.cpu().numpy(), o["vt"])
+    dx = rng.normal(size=(n, 3)).astype(np.float32); dv = rng.normal(size=(n, 3)).astype(np.float32)
+    g = T.backtrace(rif_d, res, xt, vt, _t(dx, gpu), _t(dv, gpu), h, ds, order=order)
+    with oracle.arith("factored"):
+        ob = oracle.backtrace(rif, res, o["xt"], o["vt"], dx, dv, h, ds, dtype=np.float32)
+    idx = np.flatnonzero(ob["grad"])
+    assert idx.size > 0 and idx.max() > 0.95 * rif.size            # the far end of the allocation is exercised
+    gi = g[torch.from_numpy(idx).to(gpu)].cpu().numpy()
+    assert np.isfinite(ob["grad"][idx]).all() and cases.rel_l2(gi, ob["grad"][idx]) <= 2e-5
+    assert int(torch.count_nonzero(g)) <= idx.size                  # nothing written anywhere else
+    del g, rif_d
+    torch.cuda.empty_cache()
+    with pytest.raises(RuntimeError, match="grid too large"):
+        big = torch.empty(1 << 29, dtype=torch.float32, device=gpu)
+        T.trace(big, (1024, 1024, 512), _t(pos, gpu), _t(vel, gpu), h, ds)
