@@ -265,3 +265,34 @@ def test_grid_near_the_size_limit(gpu, oracle, D):
     with pytest.raises(RuntimeError, match="grid too large"):
         big = torch.empty(1 << 29, dtype=torch.float32, device=gpu)
         T.trace(big, (1024, 1024, 512), _t(pos, gpu), _t(vel, gpu), h, ds)
+
+
+def test_many_rays_32M_equals_its_halves(gpu, D):
+    """33.5M rays in ONE call (ray index arithmetic beyond 2^24, 131k blocks, 0.4 GB per ray array): forward
+    results identical to marching the two halves separately, adjoint equal to the sum of the halves' grids."""
+    R, span = 33, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = _t(cases.smooth_field(R, seed=6), gpu).reshape(-1)
+    n = 1 << 25
+    g = torch.Generator(device=gpu).manual_seed(3)
+    pos = torch.rand(n, 3, device=gpu, generator=g) * (span * 0.96) + 0.02 * span
+    pos[:, 1] = -0.3 * ds
+    vel = torch.randn(n, 3, device=gpu, generator=g) * 0.1
+    vel[:, 1] = 1.0
+    vel /= vel.norm(dim=1, keepdim=True)
+    T = D.TracerC()
+    res = (R, R, R)
+    xt, vt = T.trace(rif, res, pos, vel, h, ds)
+    st = D.read_stats()
+    half = n // 2
+    xa, va = T.trace(rif, res, pos[:half], vel[:half], h, ds)
+    sa = D.read_stats()
+    xb, vb = T.trace(rif, res, pos[half:], vel[half:], h, ds)
+    sb = D.read_stats()
+    assert torch.equal(xt[:half], xa) and torch.equal(xt[half:], xb) and torch.equal(vt[:half], va) and torch.equal(vt[half:], vb)
+    assert st["ray_steps"] == sa["ray_steps"] + sb["ray_steps"] and st["n_failed"] == 0
+    ones = torch.ones_like(xt)
+    gfull = T.backtrace(rif, res, xt, vt, ones, ones, h, ds)
+    ga = T.backtrace(rif, res, xa, va, ones[:half], ones[:half], h, ds)
+    gb = T.backtrace(rif, res, xb, vb, ones[half:], ones[half:], h, ds)
+    assert cases.rel_l2((ga + gb).cpu().numpy(), gfull.cpu().numpy()) <= 2e-5
