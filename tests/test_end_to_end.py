@@ -23,3 +23,19 @@ def test_lens_design_loop_reduces_focus_loss(gpu):
     # the optimised medium is denser in the middle than at the rim (a focusing GRIN profile)
     c = n.shape[0] // 2
     assert float(n[c, c, c]) > float(n[c, c, 1])
+
+
+@pytest.mark.gpu
+def test_tomography_loop_recovers_the_field(gpu):
+    """examples/tomography_demo.py: device ray generation -> march -> sensor images -> MSE -> adjoint -> Adam, with
+    the multires hand-over of volume and Adam moments: the image loss and the reconstruction error must fall."""
+    import tomography_demo
+    from adjointnonlinearraytracing_amd import drrt
+    drrt.options.check_failed = False
+    drrt.options.sort_rays = True
+    n, truth, hist, err = tomography_demo.run(res_list=(9, 17), views=4, iters=40, nbins=32, verbose=False)
+    assert drrt.options.corrected_h is False                               # the demo restores the default
+    first, last = sum(hist[:3]) / 3, sum(hist[-3:]) / 3
+    assert last < 0.5 * first, (first, last)
+    assert err[-1] < 0.8 * err[0], (err[0], err[-1])
+    assert float(n.min()) >= 1.0
