@@ -49,7 +49,12 @@ last_stats: Optional[torch.Tensor] = None
 # bundle order (see include/drrt_hip.h, "visit order hand-over").
 last_order: Optional[torch.Tensor] = None
 
-_workspaces: Dict[torch.device, torch.Tensor] = {}
+# one scratch buffer per (device, stream): calls queued on different streams must not share scratch
+_workspaces: Dict[tuple, torch.Tensor] = {}
+
+
+def _wkey(device: torch.device) -> tuple:
+    return (device, torch.cuda.current_stream(device).cuda_stream)
 
 
 def _flags(adjoint: bool = False) -> int:
@@ -67,20 +72,21 @@ def _flags(adjoint: bool = False) -> int:
 
 def _workspace(n: int, flags: int, device: torch.device, nvox: int = 0) -> torch.Tensor:
     need = int(_lib.load().drrt_workspace_bytes_grid(n, nvox, flags))
-    ws = _workspaces.get(device)
+    key = _wkey(device)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
-        _quad_tokens.pop(device, None)
+        _workspaces[key] = ws
+        _quad_tokens.pop(key, None)
     if not (flags & _lib.FLAG_QUAD_GRID):
-        _quad_tokens.pop(device, None)          # this call may overwrite the region a quad copy lived in
+        _quad_tokens.pop(key, None)             # this call may overwrite the region a quad copy lived in
     return ws
 
 
 # What the quad copy in a device's workspace was built from: (rif tensor, key).  Holding the tensor keeps its
 # storage alive, so equal (data_ptr, version counter) means "same contents"; n and the sort bit fix where in
 # the workspace the copy lives.
-_quad_tokens: Dict[torch.device, tuple] = {}
+_quad_tokens: Dict[tuple, tuple] = {}
 
 
 def _march_workspace(rif_: torch.Tensor, res, n: int, h: float, ds: float, flags: int, device: torch.device,
@@ -100,10 +106,10 @@ def _march_workspace(rif_: torch.Tensor, res, n: int, h: float, ds: float, flags
     flags |= _lib.FLAG_QUAD_GRID
     ws = _workspace(n, flags, device, rif_.numel())          # may reallocate -> drops the token
     key = (rif_.data_ptr(), rif_._version, rif_.numel(), n, flags & _lib.FLAG_SORT_RAYS)
-    tok = _quad_tokens.get(device)
+    tok = _quad_tokens.get(_wkey(device))
     if paired and tok is not None and tok[1] == key:
         flags |= _lib.FLAG_QUAD_REUSE
-    _quad_tokens[device] = (rif_, key)
+    _quad_tokens[_wkey(device)] = (rif_, key)
     return flags, ws
 
 
@@ -162,7 +168,7 @@ def _capture_order(n: int, device: torch.device) -> None:
     ptr = _lib.load().drrt_last_order(C.byref(cnt))
     if not ptr or cnt.value != n:
         return
-    ws = _workspaces[device]
+    ws = _workspaces[_wkey(device)]
     off = int(ptr) - ws.data_ptr()
     if 0 <= off and off + 4 * n <= ws.numel():
         last_order = ws[off:off + 4 * n].view(torch.int32).clone()

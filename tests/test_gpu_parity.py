@@ -558,3 +558,27 @@ def test_fp16_ray_state_mode(gpu, drrt_mod):
     assert g16.dtype == torch.float32
     g32 = T.backtrace(rif, rif.shape, xt16.float(), vt16.float(), dx16.float(), dv16.float(), h, ds)
     assert cases.rel_l2(g16.cpu().numpy(), g32.cpu().numpy()) <= 2e-5
+
+
+def test_calls_follow_the_current_torch_stream(gpu, drrt_mod):
+    """Every launch, memset and sort of a call goes to the caller's stream: results on a side stream (with the
+    inputs produced on that stream just before) equal the default-stream results."""
+    R, span, n = 33, 1.0, 5000
+    h = span / (R - 1); ds = h / 2
+    rif_np = cases.smooth_field(R, seed=8)
+    pos, vel = cases.plane_rays(n, span, ds, seed=4)
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = True
+    rif = _t(rif_np, gpu)
+    ref = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+    gref = T.backtrace(rif, rif.shape, ref[0], ref[1], torch.ones_like(ref[0]), torch.ones_like(ref[0]), h, ds)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=gpu)
+    with torch.cuda.stream(side):
+        p2 = _t(pos, gpu) * 1.0                       # produced on the side stream
+        v2 = _t(vel, gpu) * 1.0
+        out = T.trace(rif, rif.shape, p2, v2, h, ds)
+        g = T.backtrace(rif, rif.shape, out[0], out[1], torch.ones_like(out[0]), torch.ones_like(out[0]), h, ds)
+    side.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    assert cases.rel_l2(g.cpu().numpy(), gref.cpu().numpy()) <= 2e-6
