@@ -469,6 +469,18 @@ __device__ __forceinline__ bool win_local(const WinCtx& W, int cx, int cy, int c
          ((unsigned)lz < (unsigned)(kWinZ - 1));
 }
 
+// ---- quad pre-reduction helpers (DPP; lanes outside the current branch read as -1 / 0) ----------------
+__device__ __forceinline__ bool quad_same_key(int key) {
+  const int k1 = __builtin_amdgcn_update_dpp(-1, key, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  const int k2 = __builtin_amdgcn_update_dpp(-1, key, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  const int k3 = __builtin_amdgcn_update_dpp(-1, key, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+  return (k1 == key) & (k2 == key) & (k3 == key);
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  return v;
+}
 // add all 8 accumulated corners of the lane's cell; returns true when the LDS window took them
 __device__ __forceinline__ bool emit8(const WinCtx& W, int cx, int cy, int cz, int base,
                                       float a000, float a100, float a010, float a110,
@@ -516,9 +528,18 @@ __device__ __forceinline__ bool shift_emit4(const WinCtx& W, int cx, int cy, int
   const bool inw = win_local(W, cx, cy, cz, lidx);
   if (inw) {
     if (W.experiment != 3) {
-      win_t* q = W.win + lidx + (fwd ? 0 : la);
-      atomicAdd(q, (win_t)e0); atomicAdd(q + lp, (win_t)e1); atomicAdd(q + lq, (win_t)e2);
-      atomicAdd(q + lq + lp, (win_t)e3);
+      const int qi = lidx + (fwd ? 0 : la);
+      // Quad pre-reduction: sorted rays put the 4 lanes of a quad in the same cell, crossing the same face in the
+      // same step, most of the time -- then the four lanes' values go to the same four LDS slots.  One lane adds
+      // the quad's sums instead of four lanes colliding on each slot.  (DPP reads of lanes that are not in this
+      // branch return -1 / 0, so a partly active quad simply does not qualify.)
+      const bool same = quad_same_key(qi | (axis << 16));
+      const float s0 = quad_sum(e0), s1 = quad_sum(e1), s2 = quad_sum(e2), s3 = quad_sum(e3);
+      if (!same || (threadIdx.x & 3) == 0) {
+        win_t* q = W.win + qi;
+        atomicAdd(q, (win_t)(same ? s0 : e0)); atomicAdd(q + lp, (win_t)(same ? s1 : e1));
+        atomicAdd(q + lq, (win_t)(same ? s2 : e2)); atomicAdd(q + lq + lp, (win_t)(same ? s3 : e3));
+      }
     }
   } else if (W.experiment != 2) {
     float* g = W.grad + base + (fwd ? 0 : ga);
