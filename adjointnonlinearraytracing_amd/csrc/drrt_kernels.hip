@@ -529,16 +529,31 @@ __device__ __forceinline__ bool shift_emit4(const WinCtx& W, int cx, int cy, int
   if (inw) {
     if (W.experiment != 3) {
       const int qi = lidx + (fwd ? 0 : la);
-      // Quad pre-reduction: sorted rays put the 4 lanes of a quad in the same cell, crossing the same face in the
-      // same step, most of the time -- then the four lanes' values go to the same four LDS slots.  One lane adds
-      // the quad's sums instead of four lanes colliding on each slot.  (DPP reads of lanes that are not in this
-      // branch return -1 / 0, so a partly active quad simply does not qualify.)
-      const bool same = quad_same_key(qi | (axis << 16));
-      const float s0 = quad_sum(e0), s1 = quad_sum(e1), s2 = quad_sum(e2), s3 = quad_sum(e3);
-      if (!same || (threadIdx.x & 3) == 0) {
+      // Pair / quad pre-reduction: sorted rays put the 4 lanes of a quad in the same cell, crossing the same face in
+      // the same step, most of the time -- then the lanes' values go to the same four LDS slots.  One lane adds the
+      // quad's sums (or one lane per pair the pair's sums) instead of all lanes colliding on each slot.  (DPP reads
+      // of lanes that are not in this branch return -1 / 0, so a partly active quad or pair does not qualify.)
+      const int key = qi | (axis << 16);
+      const int k1 = __builtin_amdgcn_update_dpp(-1, key, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+      const int k2 = __builtin_amdgcn_update_dpp(-1, key, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+      const int k3 = __builtin_amdgcn_update_dpp(-1, key, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+      const bool psame = k1 == key;                                  // my pair partner goes to the same slots
+      const bool same = psame & (k2 == key) & (k3 == key);           // the whole quad does
+      float p0 = e0, p1 = e1, p2 = e2, p3 = e3;                      // pair sums, then quad sums
+      p0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p0), 0xB1, 0xF, 0xF, false));
+      p1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p1), 0xB1, 0xF, 0xF, false));
+      p2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p2), 0xB1, 0xF, 0xF, false));
+      p3 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p3), 0xB1, 0xF, 0xF, false));
+      const float s0 = p0 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p0), 0x4E, 0xF, 0xF, false));
+      const float s1 = p1 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p1), 0x4E, 0xF, 0xF, false));
+      const float s2 = p2 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p2), 0x4E, 0xF, 0xF, false));
+      const float s3 = p3 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p3), 0x4E, 0xF, 0xF, false));
+      const unsigned ql = threadIdx.x & 3u;
+      const bool add = same ? ql == 0u : (psame ? (ql & 1u) == 0u : true);
+      if (add) {
         win_t* q = W.win + qi;
-        atomicAdd(q, (win_t)(same ? s0 : e0)); atomicAdd(q + lp, (win_t)(same ? s1 : e1));
-        atomicAdd(q + lq, (win_t)(same ? s2 : e2)); atomicAdd(q + lq + lp, (win_t)(same ? s3 : e3));
+        atomicAdd(q, (win_t)(same ? s0 : (psame ? p0 : e0)));      atomicAdd(q + lp, (win_t)(same ? s1 : (psame ? p1 : e1)));
+        atomicAdd(q + lq, (win_t)(same ? s2 : (psame ? p2 : e2))); atomicAdd(q + lq + lp, (win_t)(same ? s3 : (psame ? p3 : e3)));
       }
     }
   } else if (W.experiment != 2) {
