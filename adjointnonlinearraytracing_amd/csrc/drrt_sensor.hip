@@ -64,21 +64,49 @@ __device__ __forceinline__ SensorRay sensor_locate(const SensorArgs& a, size_t i
 // the block's smallest hit pixel and flushes it with one global atomic per touched pixel; taps
 // outside the tile go to global memory directly.
 constexpr int kTile = 48;                       // tile edge in pixels (48*48 doubles = 18 KiB)
+constexpr int kVoteCell = 32, kVote = 40;       // anchor vote: 40x40 coarse cells of 32 pixels (images up to 1277^2; larger ones clamp)
 
 __global__ void __launch_bounds__(256) k_sensor_splat(SensorArgs a) {
   __shared__ double s_tile[kTile * kTile];
+  __shared__ unsigned s_vote[kVote * kVote];
   __shared__ int s_min[2];
+  __shared__ unsigned s_best;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   for (int k = threadIdx.x; k < kTile * kTile; k += 256) s_tile[k] = 0.0;
+  for (int k = threadIdx.x; k < kVote * kVote; k += 256) s_vote[k] = 0u;
   if (threadIdx.x < 2) s_min[threadIdx.x] = 0x7fffffff;
+  if (threadIdx.x == 0) s_best = 0u;
   __syncthreads();
   float x[3], v[3];
   SensorRay r;
   r.ok = false; r.i1[0] = r.i1[1] = 0; r.u[0] = r.u[1] = 0.f; r.F = 0.f; r.den = 1.f; r.t = 0.f;
   if (i < a.n_rays) r = sensor_locate(a, i, x, v);
-  if (r.ok) { atomicMin(&s_min[0], r.i1[0] - 1); atomicMin(&s_min[1], r.i1[1] - 1); }
+  // Tile anchor.  If all the block's hits fit one tile, anchor at the smallest hit pixel.  Otherwise (a focused
+  // bundle plus stray rays: the min corner would leave the FOCUS outside the tile, on the slow same-address
+  // global atomics) the rays vote on a coarse kVoteCell-pixel grid and the tile is centred on the winning cell.
+  int ca = 0, cb = 0;
+  if (r.ok) {
+    atomicMin(&s_min[0], r.i1[0] - 1); atomicMin(&s_min[1], r.i1[1] - 1);
+    ca = min(max((r.i1[0] + 3) / kVoteCell, 0), kVote - 1); cb = min(max((r.i1[1] + 3) / kVoteCell, 0), kVote - 1);
+    atomicAdd(&s_vote[ca * kVote + cb], 1u);
+  }
   __syncthreads();
-  const int oa = s_min[0], ob = s_min[1];       // tile origin (block-uniform)
+  {
+    // argmax over the votes: pack (count, cell) so that atomicMax picks the fullest cell
+    unsigned best = 0u;
+    for (int k = threadIdx.x; k < kVote * kVote; k += 256) best = max(best, (s_vote[k] << 12) | (unsigned)k);
+    if (best >> 12) atomicMax(&s_best, best);
+  }
+  __syncthreads();
+  int oa = s_min[0], ob = s_min[1];             // tile origin (block-uniform)
+  {
+    const int wa = (int)((s_best & 0xfffu) / kVote), wb = (int)((s_best & 0xfffu) % kVote);
+    const int va = wa * kVoteCell - 3 - (kTile - kVoteCell) / 2, vb = wb * kVoteCell - 3 - (kTile - kVoteCell) / 2;
+    // keep the min-corner anchor when it already covers the winning cell entirely
+    if (va + (kTile - kVoteCell) / 2 + kVoteCell + 3 > oa + kTile || vb + (kTile - kVoteCell) / 2 + kVoteCell + 3 > ob + kTile) {
+      oa = va; ob = vb;
+    }
+  }
   if (r.ok) {
     float w[16], wsum = 0.f;
 #pragma unroll
@@ -92,8 +120,8 @@ __global__ void __launch_bounds__(256) k_sensor_splat(SensorArgs a) {
       }
     }
     const float scale = r.F / wsum;                                     // grid.py:145 (all 16 taps)
-    const int la = r.i1[0] - 1 - oa, lb = r.i1[1] - 1 - ob;             // tile coords of the first tap (>= 0)
-    const bool in_tile = (la + 3 < kTile) & (lb + 3 < kTile);
+    const int la = r.i1[0] - 1 - oa, lb = r.i1[1] - 1 - ob;             // tile coords of the first tap
+    const bool in_tile = (la >= 0) & (lb >= 0) & (la + 3 < kTile) & (lb + 3 < kTile);
 #pragma unroll
     for (int ja = 0; ja < 4; ++ja) {
       const int ia = r.i1[0] - 1 + ja;
