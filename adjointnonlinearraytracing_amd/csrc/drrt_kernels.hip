@@ -775,8 +775,31 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_cable(CableArgs a) {
     const float dxx[3] = {gxv.x, gxv.y, gxv.z}, dvv[3] = {gvv.x, gvv.y, gvv.z};
     unsigned steps = cable_backtrace_ray(C, a.ds, a.max_steps, pp, vv, dxx, dvv,
       [s_grad, gacc, use_lds](int i0, int i1, float a0, float a1) {
-        if (use_lds) { atomicAdd(&s_grad[i0], (double)a0); atomicAdd(&s_grad[i1], (double)a1); }   // ds_add_f64
-        else { atomic_add_f32(&gacc[i0], a0); atomic_add_f32(&gacc[i1], a1); }
+        if (use_lds) {
+          // Rays in source-pixel order sit at nearly the same radius as their neighbours: lanes of a pair / quad
+          // then hit the same two bins, and a pair / quad pre-reduction (as in shift_emit4) halves the time.  For
+          // rays in random order it would only cost instructions, so it runs when at least a quarter of the wave's
+          // lanes have a matching partner (wave-uniform decision).
+          const int key = i0 | (i1 << 16);
+          const int k1 = __builtin_amdgcn_update_dpp(-1, key, 0xB1, 0xF, 0xF, false);
+          const bool psame = k1 == key;
+          if (__popcll(__ballot(psame)) >= 16) {
+            const int k2 = __builtin_amdgcn_update_dpp(-1, key, 0x4E, 0xF, 0xF, false);
+            const int k3 = __builtin_amdgcn_update_dpp(-1, key, 0x1B, 0xF, 0xF, false);
+            const bool same = psame & (k2 == key) & (k3 == key);
+            const float p0 = a0 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0xB1, 0xF, 0xF, false));
+            const float p1 = a1 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1), 0xB1, 0xF, 0xF, false));
+            const float s0 = p0 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p0), 0x4E, 0xF, 0xF, false));
+            const float s1 = p1 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p1), 0x4E, 0xF, 0xF, false));
+            const unsigned ql = threadIdx.x & 3u;
+            if (same ? ql == 0u : (psame ? (ql & 1u) == 0u : true)) {
+              atomicAdd(&s_grad[i0], (double)(same ? s0 : (psame ? p0 : a0)));                   // ds_add_f64
+              atomicAdd(&s_grad[i1], (double)(same ? s1 : (psame ? p1 : a1)));
+            }
+          } else {
+            atomicAdd(&s_grad[i0], (double)a0); atomicAdd(&s_grad[i1], (double)a1);
+          }
+        } else { atomic_add_f32(&gacc[i0], a0); atomic_add_f32(&gacc[i1], a1); }
       });
     steps_tot += steps; steps_max = max(steps_max, steps);
   }
