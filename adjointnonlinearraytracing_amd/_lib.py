@@ -62,6 +62,7 @@ SIGNATURES = {
     "drrt_gen_rays_f32": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drrt_last_order": (_vp, [_vp]),
     "drrt_set_order_hint": (None, [_vp, _sz]),
+    "drrt_order_hint_pending": (_sz, []),
     "drrt_profile_begin": (_i, [_i]),
     "drrt_profile_collect": (_i, [_vp, _vp, _i]),
     "drrt_profile_end": (None, []),

@@ -289,6 +289,20 @@ DRRT_HD void fwd_step_c(const Vol& V, const float* __restrict__ sdf, float ds, F
   s.inside = cur_inside;                                                    // :86
 }
 
+// trace_plane, for a ray that has just been flagged escaped: can it produce ANOTHER exit record later?
+// The reference keeps marching escaped rays while its global loop runs (src/tracer.cpp:130-160) and records
+// EVERY inside -> outside transition, so a ray that can come back into {in bounds, not past the plane} may
+// overwrite its exit record later.  An escaped ray flies straight (its gathers are masked), hence it can
+// NOT come back when it is outside the box moving away (volume::escaped), or past the plane and not
+// approaching it.  Anything else -- in practice only a ray that STARTS past the plane and heads back
+// through it -- is flagged and re-marched over the global loop count by ray_full<1>.
+DRRT_HD bool plane_again(const Vol& V, const FwdState& s) {
+  const float d = dot3(s.x - s.aux0, s.y - s.aux1, s.z - s.aux2, s.aux3, s.aux4, s.aux5);
+  const float dv = dot3(s.vx, s.vy, s.vz, s.aux3, s.aux4, s.aux5);
+  const bool gone = escaped(V, s.x, s.y, s.z, s.vx, s.vy, s.vz) | ((d > 0.f) & (dv >= 0.f));
+  return !gone;
+}
+
 template <int MODE>
 DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s, Cell& c) {
   Taps t;
@@ -474,18 +488,7 @@ DRRT_HD RayOut trace_ray(const Vol& V, const float* __restrict__ sdf, float ds, 
   RayOut o;
   o.xt[0] = s.xtx; o.xt[1] = s.xty; o.xt[2] = s.xtz; o.vt[0] = s.vtx; o.vt[1] = s.vty; o.vt[2] = s.vtz;
   o.dist2 = 0.f; o.esc = s.esc; o.act = act; o.steps = steps; o.again = false;
-  if (MODE == 1 && s.esc) {
-    // The reference keeps marching escaped rays while its global loop runs (:130-160) and records EVERY
-    // inside -> outside transition, so a ray that can come back into {in bounds, not past the plane} may
-    // overwrite its exit record later.  An escaped ray flies straight (its gathers are masked), hence it can
-    // NOT come back when it is outside the box moving away (volume::escaped), or past the plane and not
-    // approaching it.  Anything else -- in practice only a ray that STARTS past the plane and heads back
-    // through it -- is flagged and re-marched over the global loop count by plane_ray_full.
-    const float d = dot3(s.x - s.aux0, s.y - s.aux1, s.z - s.aux2, s.aux3, s.aux4, s.aux5);
-    const float dv = dot3(s.vx, s.vy, s.vz, s.aux3, s.aux4, s.aux5);
-    const bool gone = escaped(V, s.x, s.y, s.z, s.vx, s.vy, s.vz) | ((d > 0.f) & (dv >= 0.f));
-    o.again = !gone;
-  }
+  if (MODE == 1 && s.esc) o.again = plane_again(V, s);
   if (MODE == 2 && s.esc && s.inside) {
     // trace_sdf: the ray left the BOX (volume::escaped) while the clamped sdf sample still reads negative.  The
     // reference keeps marching it -- still "inside", still refracted by clamped samples -- and records the

@@ -52,6 +52,14 @@ __device__ __forceinline__ void block_stats(drrt_stats* stats, unsigned steps, u
   }
 }
 
+// Ray visited by thread t: through the visit order when there is one.  An index outside [0, n) -- only possible
+// with a corrupt caller-supplied order hint -- is skipped (that slot's outputs stay unwritten), never dereferenced.
+__device__ __forceinline__ bool ray_index(const uint32_t* __restrict__ perm, size_t t, size_t n, size_t& i) {
+  if (t >= n) return false;
+  i = perm ? (size_t)perm[t] : t;
+  return i < n;
+}
+
 struct Ray3 { float x, y, z; };
 // Ray arrays are (n,3) row-major, fp32 or -- for the *_f16io entry points ("fp16 ray state", config 5
 // of BASELINE.json) -- IEEE half.  Half values are widened exactly on load; the march, the adjoint
@@ -96,8 +104,8 @@ template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
   unsigned steps = 0, failed = 0;
-  if (t < a.n) {
-    const size_t i = a.perm ? (size_t)a.perm[t] : t;
+  size_t i;
+  if (ray_index(a.perm, t, a.n, i)) {
     Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
     const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
     float po[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
@@ -225,9 +233,9 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
   FwdState s;
   s.x = s.y = s.z = s.vx = s.vy = s.vz = 0.f;
   s.aux0 = s.aux1 = s.aux2 = s.aux3 = s.aux4 = s.aux5 = 0.f;
-  bool live = t < a.n;
+  bool live = ray_index(a.perm, t, a.n, i);
+  const bool mine = live;
   if (live) {
-    i = a.perm ? (size_t)a.perm[t] : t;
     Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
     s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
     if (MODE == 1) {
@@ -281,12 +289,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
     }
   }
   unsigned failed = 0;
-  if (t < a.n) {
+  if (mine) {
     if (!s.esc) { s.xtx = s.x; s.xty = s.y; s.xtz = s.z; }                  // :95 (vt stays, Q6)
     failed = s.esc ? 0u : 1u;
     st3(a.xt, i, s.xtx, s.xty, s.xtz, a.io_half);
     st3(a.vt, i, s.vtx, s.vty, s.vtz, a.io_half);
-    if (MODE == 1) a.failmask[i] = s.esc ? 0 : 1;                           // src/tracer.cpp:171
+    // src/tracer.cpp:171; bit 1 = "may record a later exit": re-marched by k_trace_again (same test as trace_ray)
+    if (MODE == 1) a.failmask[i] = (s.esc ? 0 : 1) | ((s.esc && plane_again(V, s)) ? 2 : 0);
   }
   block_stats(a.stats, steps, failed);
 }
@@ -310,8 +319,8 @@ struct TargetArgs {
 __global__ void __launch_bounds__(kBlock) k_target_a(TargetArgs a) {
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
   unsigned steps = 0, failed = 0;
-  if (t < a.n) {
-    const size_t i = a.perm ? (size_t)a.perm[t] : t;
+  size_t i;
+  if (ray_index(a.perm, t, a.n, i)) {
     Ray3 p = ld3(a.pos, i), u = ld3(a.vel, i), tg = ld3(a.target, i);
     const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z}, tt[3] = {tg.x, tg.y, tg.z};
     float cont[6];
@@ -367,8 +376,8 @@ template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
   unsigned steps = 0;
-  if (t < a.n) {
-    const size_t i = a.perm ? (size_t)a.perm[t] : t;
+  size_t i;
+  if (ray_index(a.perm, t, a.n, i)) {
     Ray3 p = ld3(a.xt, i, a.io_half), u = ld3(a.vt, i, a.io_half), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
     const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
     const float dxx[3] = {gxv.x, gxv.y, gxv.z}, dvv[3] = {gvv.x, gvv.y, gvv.z};
@@ -589,8 +598,8 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
   AdjState s;
   s.active = false;
-  if (t < a.n) {
-    const size_t i = a.perm ? (size_t)a.perm[t] : t;
+  size_t i;
+  if (ray_index(a.perm, t, a.n, i)) {
     Ray3 p = ld3(a.xt, i, a.io_half), u = ld3(a.vt, i, a.io_half), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
     s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
     adj_init(V, a.ds, gxv.x, gxv.y, gxv.z, gvv.x, gvv.y, gvv.z, s);
@@ -849,11 +858,21 @@ static thread_local size_t g_last_order_n = 0;
 static thread_local const uint32_t* g_hint_order = nullptr;   // order to use in the NEXT march call
 static thread_local size_t g_hint_n = 0;
 
+// Every march entry point takes (reads AND clears) the hint as its FIRST statement, so no return path --
+// validation failure included -- can leave a stale device pointer armed for a later call.
+struct OrderHint { const uint32_t* order; size_t n; };
+static inline OrderHint take_hint() {
+  OrderHint h{g_hint_order, g_hint_n};
+  g_hint_order = nullptr; g_hint_n = 0;
+  return h;
+}
+
 extern "C" const uint32_t* drrt_last_order(size_t* n_out) {
   if (n_out) *n_out = g_last_order_n;
   return g_last_order;
 }
-extern "C" void drrt_set_order_hint(const uint32_t* order, size_t n) { g_hint_order = order; g_hint_n = n; }
+extern "C" void drrt_set_order_hint(const uint32_t* order, size_t n) { g_hint_order = order; g_hint_n = order ? n : 0; }
+extern "C" size_t drrt_order_hint_pending(void) { return g_hint_order ? g_hint_n : 0; }
 
 // ---- optional per-kernel timing (bench / profiling aid; not thread-safe) --------------------
 // Event pairs are recorded on the call's stream right around a kernel launch; nothing
@@ -991,13 +1010,12 @@ static int zero_stats(drrt_stats* stats, hipStream_t s) {
 
 static int maybe_sort(const Vol& V, float h, size_t n, const void* pos, const void* vel, float dir_sign,
                       unsigned flags, void* ws, size_t ws_bytes, const uint32_t** perm, hipStream_t s,
-                      int io_half = 0) {
+                      OrderHint hint, int io_half = 0) {
   *perm = nullptr;
-  // a hint from the caller (normally the paired forward call's order) replaces the sort; it is
-  // consumed by this call whether or not it is usable
-  const uint32_t* hint = g_hint_order; const size_t hint_n = g_hint_n;
-  g_hint_order = nullptr; g_hint_n = 0;
-  if (hint && hint_n == n) { *perm = hint; return DRRT_OK; }
+  // a hint from the caller (normally the paired forward call's order) replaces the sort; it was consumed
+  // by this call at its entry (take_hint) whether or not it is usable.  Entries are range-checked on the
+  // device (ray_index), so a wrong hint can leave rays unvisited but cannot make a kernel fault.
+  if (hint.order && hint.n == n) { *perm = hint.order; return DRRT_OK; }
   if (!(flags & DRRT_FLAG_SORT_RAYS) || n < 2) return DRRT_OK;
   if (!ws || ws_bytes < sort_workspace_bytes(n)) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_SORT_RAYS");
   ProfScope prof(DRRT_PROF_SORT, s);
@@ -1016,6 +1034,7 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
                      const void* pos, const void* vel, const float* pln_o, const float* pln_d,
                      float h, float ds, void* xt, void* vt, uint8_t* failmask, drrt_stats* stats,
                      void* ws, size_t ws_bytes, unsigned flags, void* stream, int io_half = 0) {
+  const OrderHint hint = take_hint();
   g_err[0] = 0;
   hipStream_t s = (hipStream_t)stream;
   TraceArgs a{};
@@ -1024,15 +1043,23 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
   if (n == 0) return zero_stats(stats, s);
   if (!pos || !vel || !xt || !vt) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (MODE == 1 && (!pln_o || !pln_d || !failmask)) return fail(DRRT_ERR_ARG, "null plane/failmask pointer");
-  if ((MODE == 1 || MODE == 2) && !stats) {   // the second pass needs the global loop count: library-owned block
-    static drrt_stats* priv = nullptr;
-    if (!priv) { hipError_t e = hipMalloc((void**)&priv, sizeof(drrt_stats)); if (e != hipSuccess) return fail_hip(e, "hipMalloc(stats)"); }
-    stats = priv;
+  if ((MODE == 1 || MODE == 2) && !stats) {
+    // the second pass needs the global loop count: library-owned block, one per device (allocated once).  It is
+    // shared by every stream of that device: callers that run trace_pln / trace_sdf concurrently on several streams
+    // of one device must pass their own stats block.
+    constexpr int kMaxDev = 64;
+    static drrt_stats* priv[kMaxDev] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDev) return fail(DRRT_ERR_ARG, "device ordinal out of range; pass a stats block");
+    if (!priv[dev]) { e = hipMalloc((void**)&priv[dev], sizeof(drrt_stats)); if (e != hipSuccess) return fail_hip(e, "hipMalloc(stats)"); }
+    stats = priv[dev];
   }
   if (MODE == 2 && !sdf) return fail(DRRT_ERR_ARG, "null sdf pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
   rc = zero_stats(stats, s); if (rc) return rc;
-  rc = maybe_sort(a.vol, h, n, pos, vel, 1.f, flags, ws, ws_bytes, &a.perm, s, io_half); if (rc) return rc;
+  rc = maybe_sort(a.vol, h, n, pos, vel, 1.f, flags, ws, ws_bytes, &a.perm, s, hint, io_half); if (rc) return rc;
   if (!(flags & DRRT_FLAG_LDS_BRICKS)) { rc = maybe_quad(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc; }
   if (MODE == 2) {                      // n flag bytes, in the slack the workspace keeps after the sort buffers
     const size_t off = (flags & DRRT_FLAG_SORT_RAYS) ? align_up(sort_workspace_bytes(n), 256) : 0;
@@ -1093,6 +1120,8 @@ extern "C" int drrt_trace_target_f32(const float* rif, long long nvox, const int
                                      float h, float ds, float* xt, float* vt, float* dist2,
                                      drrt_stats* stats, void* ws, size_t ws_bytes, unsigned flags,
                                      void* stream) {
+  (void)take_hint();     // never honoured here: the phase-A state buffer at the start of the workspace would overlay
+                         // an order that lives in the same workspace (drrt_last_order() of an earlier call)
   g_err[0] = 0;
   hipStream_t s = (hipStream_t)stream;
   TargetArgs a{};
@@ -1108,7 +1137,8 @@ extern "C" int drrt_trace_target_f32(const float* rif, long long nvox, const int
   if (!ws || ws_bytes < state_bytes + sort_bytes) return fail(DRRT_ERR_ARG, "workspace too small for trace_target");
   rc = zero_stats(stats, s); if (rc) return rc;
   a.state = (float*)ws;
-  rc = maybe_sort(a.vol, h, n, pos, vel, 1.f, flags, (char*)ws + state_bytes, ws_bytes - state_bytes, &a.perm, s);
+  rc = maybe_sort(a.vol, h, n, pos, vel, 1.f, flags, (char*)ws + state_bytes, ws_bytes - state_bytes, &a.perm, s,
+                  OrderHint{nullptr, 0});
   if (rc) return rc;
   a.pos = pos; a.vel = vel; a.target = target; a.xt = xt; a.vt = vt; a.dist2 = dist2;
   a.stats = stats; a.n = n; a.ds = ds; a.max_steps = steps_fwd(h, res, ds);
@@ -1124,6 +1154,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
                          const void* xt, const void* vt, const void* dx, const void* dv,
                          float h, float ds, float* grad, drrt_stats* stats, void* ws, size_t ws_bytes,
                          unsigned flags, void* stream, int io_half = 0) {
+  const OrderHint hint = take_hint();
   g_err[0] = 0;
   hipStream_t s = (hipStream_t)stream;
   BackArgs a{};
@@ -1140,7 +1171,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   if (n == 0) return DRRT_OK;
   if (!xt || !vt || !dx || !dv) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
-  rc = maybe_sort(a.vol, h, n, xt, vt, -1.f, flags, ws, ws_bytes, &a.perm, s, io_half); if (rc) return rc;
+  rc = maybe_sort(a.vol, h, n, xt, vt, -1.f, flags, ws, ws_bytes, &a.perm, s, hint, io_half); if (rc) return rc;
   rc = maybe_quad(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc;
   a.io_half = io_half;
   a.sdf = sdf; a.xt = xt; a.vt = vt; a.dx = dx; a.dv = dv; a.grad = grad; a.stats = stats;
@@ -1199,6 +1230,7 @@ extern "C" int drrt_trace_cable_f32(const float* rif, size_t rres, float radius,
                                     float* xt, float* vt, float* dist2, drrt_stats* stats, void* ws,
                                     size_t ws_bytes, unsigned flags, void* stream) {
   (void)ws; (void)ws_bytes; (void)flags;
+  (void)take_hint();     // the cable kernels visit rays in caller order
   g_err[0] = 0;
   hipStream_t s = (hipStream_t)stream;
   if (!rif) return fail(DRRT_ERR_ARG, "null rif pointer");
@@ -1224,6 +1256,7 @@ extern "C" int drrt_backtrace_cable_f32(const float* rif, size_t rres, float rad
                                         float ds, float* grad, drrt_stats* stats, void* ws, size_t ws_bytes,
                                         unsigned flags, void* stream) {
   (void)ws; (void)ws_bytes;
+  (void)take_hint();
   g_err[0] = 0;
   hipStream_t s = (hipStream_t)stream;
   if (!rif || !grad) return fail(DRRT_ERR_ARG, "null rif/grad pointer");

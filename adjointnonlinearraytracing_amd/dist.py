@@ -59,33 +59,44 @@ def allreduce_grad(grad: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def _hip_trace(rif_flat, shape, x, v, h, ds):
+    """-> (xt, vt, order): the forward's visit order rides along so the sharded adjoint can reuse it."""
     from . import drrt
-    return drrt.TracerC().trace(rif_flat, shape, x, v, h, ds)
+    xt, vt = drrt.TracerC().trace(rif_flat, shape, x, v, h, ds)
+    return xt, vt, drrt.last_order
 
 
-def _hip_backtrace(rif_flat, shape, xt, vt, gx, gv, h, ds):
+def _hip_backtrace(rif_flat, shape, xt, vt, gx, gv, h, ds, order=None):
     from . import drrt
-    return drrt.TracerC().backtrace(rif_flat, shape, xt, vt, gx, gv, h, ds)
+    return drrt.TracerC().backtrace(rif_flat, shape, xt, vt, gx, gv, h, ds, order=order)
 
 
 class ShardedBackTracerC(torch.autograd.Function):
     """``BackTracerC`` (core/tracer.py:294-335) over this rank's ray shard; backward all-reduces
     dL/dn so every rank returns the gradient of the GLOBAL ray set.
 
-    ``apply(rif, x_local, v_local, h, ds, group=None, trace_fn=None, backtrace_fn=None)``"""
+    ``apply(rif, x_local, v_local, h, ds, group=None, trace_fn=None, backtrace_fn=None)``
+
+    ``trace_fn(rif_flat, shape, x, v, h, ds)`` returns ``(xt, vt)`` or ``(xt, vt, order)``; a non-None
+    ``order`` (the visit order the forward sorted this shard's rays into) is handed to
+    ``backtrace_fn(..., order=order)`` exactly as ``tracer.BackTracerC`` does on one GPU, so the sharded
+    adjoint runs the same fast path (no re-sort by exit rays)."""
 
     @staticmethod
     def forward(ctx, rif, x, v, h, ds, group=None,
                 trace_fn: Optional[Callable] = None, backtrace_fn: Optional[Callable] = None):
         ctx.shape = rif.shape
-        ctx.rif = rif.detach().flatten()
         ctx.h, ctx.ds, ctx.group = h, ds, group
         ctx.backtrace_fn = backtrace_fn or _hip_backtrace
-        ctx.outx, ctx.outv = (trace_fn or _hip_trace)(ctx.rif, ctx.shape, x.detach(), v.detach(), h, ds)
-        return ctx.outx.clone(), ctx.outv.clone()
+        out = (trace_fn or _hip_trace)(rif.detach().flatten(), ctx.shape, x.detach(), v.detach(), h, ds)
+        outx, outv = out[0], out[1]
+        ctx.order = out[2] if len(out) > 2 else None
+        ctx.save_for_backward(rif, outx, outv)          # version-checked: no silent use of a modified grid
+        return outx, outv
 
     @staticmethod
     def backward(ctx, grad_x, grad_v):
-        drif = ctx.backtrace_fn(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v, ctx.h, ctx.ds)
+        rif, outx, outv = ctx.saved_tensors
+        kw = {} if ctx.order is None else {"order": ctx.order}
+        drif = ctx.backtrace_fn(rif.detach().flatten(), ctx.shape, outx, outv, grad_x, grad_v, ctx.h, ctx.ds, **kw)
         drif = allreduce_grad(drif.reshape(*ctx.shape).contiguous(), ctx.group)
         return drif, None, None, None, None, None, None, None

@@ -29,7 +29,8 @@ from . import _lib
 class Options:
     sort_rays: bool = True        # locality-sort rays by entry voxel (DRRT_FLAG_SORT_RAYS)
     corrected_h: bool = False     # adjoint: divide gradient splat by h; default = as written
-    check_failed: bool = True     # sync + print "failed to exit all rays" like src/tracer.cpp:89-90
+    check_failed: bool = True     # print "failed to exit all rays" like src/tracer.cpp:89-90 (asynchronously: no host
+                                  # sync per call; the message may appear one call late -- see flush_warnings())
     direct_atomics: bool = False  # adjoint: one global atomic per tap (debug / A-B)
     lds_bricks: bool = False      # forward: opt-in LDS-staged bricks of the grid (bit-identical; slower on MI355X)
     quad_grid: object = False     # opt-in 16-byte "quad" copy of the grid in the workspace (DRRT_FLAG_QUAD_GRID):
@@ -179,9 +180,57 @@ def _hint(order: Optional[torch.Tensor], n: int) -> None:
         _lib.load().drrt_set_order_hint(C.c_void_p(order.data_ptr()), n)
 
 
+def _clear_hint() -> None:
+    """The library consumes a hint at the entry of the next march call; this covers the paths on which that call
+    is never reached (an exception while marshalling arguments)."""
+    _lib.load().drrt_set_order_hint(None, 0)
+
+
+# "failed to exit all rays" (src/tracer.cpp:90) without a host sync per call: the stats block is copied to pinned
+# host memory asynchronously behind the kernels, and looked at when the copy has landed -- at the next tracer call,
+# at flush_warnings(), or at interpreter exit.  The message can therefore appear one call late; it is never lost.
+_pending_warn: list = []      # (event, pinned host tensor)
+_pinned_pool: list = []
+
+
+def _drain_warnings(block: bool = False) -> None:
+    while _pending_warn and (block or _pending_warn[0][0].query()):
+        ev, host = _pending_warn.pop(0)
+        if block:
+            ev.synchronize()
+        if int(host[1]) > 0:
+            print("failed to exit all rays")            # src/tracer.cpp:90
+        _pinned_pool.append(host)
+
+
+def flush_warnings() -> None:
+    """Wait for the outstanding marches and print any pending "failed to exit all rays" message."""
+    _drain_warnings(block=True)
+
+
+def _at_exit() -> None:
+    try:
+        if _pending_warn:
+            _drain_warnings(block=True)
+    except Exception:              # the HIP runtime may already be gone at interpreter teardown
+        pass
+
+
+import atexit as _atexit   # noqa: E402
+_atexit.register(_at_exit)
+
+
 def _warn_failed(stats: torch.Tensor) -> None:
-    if options.check_failed and int(stats[1].item()) > 0:
-        print("failed to exit all rays")            # src/tracer.cpp:90
+    _drain_warnings()
+    if not options.check_failed:
+        return
+    host = _pinned_pool.pop() if _pinned_pool else torch.empty(3, dtype=torch.int64, pin_memory=True)
+    host.copy_(stats, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(stats.device))
+    _pending_warn.append((ev, host))
+    if len(_pending_warn) > 64:                          # bounded backlog
+        _drain_warnings(block=True)
 
 
 def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -299,11 +348,14 @@ class TracerC:
             grad = torch.empty_like(rif_)
             fl = _flags(adjoint=True)
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None), _new_stats(dev)
-            _hint(order, n)
             fn = _lib.load().drrt_backtrace_f16io if half else _lib.load().drrt_backtrace_f32
-            _lib.check(fn(
-                _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
-                float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+            try:
+                _hint(order, n)
+                _lib.check(fn(
+                    _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
+                    float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+            finally:
+                _clear_hint()
         return grad
 
     def backtrace_sdf(self, rif, sdf, res, xt, vt, dx, dv, h, ds, order: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -319,10 +371,13 @@ class TracerC:
             grad = torch.empty_like(rif_)
             fl = _flags(adjoint=True)
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None), _new_stats(dev)
-            _hint(order, n)
-            _lib.check(_lib.load().drrt_backtrace_sdf_f32(
-                _p(rif_), _p(sdf_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
-                float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+            try:
+                _hint(order, n)
+                _lib.check(_lib.load().drrt_backtrace_sdf_f32(
+                    _p(rif_), _p(sdf_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
+                    float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+            finally:
+                _clear_hint()
         return grad
 
     def backtrace_cable(self, rif, radius, length, xt, vt, dx, dv, ds) -> torch.Tensor:

@@ -4,7 +4,10 @@
 
 Contract reproduced from the reference:
   * forward inputs are detached, flattened C-order and narrowed to fp32 (``:299-301``);
-  * forward stores ``rif``, the exit rays and the scalars on ``ctx`` and returns fresh tensors;
+  * forward keeps ``rif``, the exit rays and the scalars for backward and returns fresh tensors.  The reference
+    snapshots the grid (``FloatC(rif.flatten())`` copies, ``:299``); here ``rif`` and the exit rays are kept with
+    ``ctx.save_for_backward`` -- no copies, and autograd's version check turns an in-place update of ``rif`` (or of
+    the returned exit rays) between forward and backward into a RuntimeError instead of a silently wrong gradient;
   * backward returns ``drif`` reshaped to ``rif.shape`` and ``None`` for every other input
     (no gradient w.r.t. ``x``, ``v``: ``:335,386,432,479,526``);
   * ``BackPlaneTracerC`` / ``BackTargetTracerC`` backward run the GENERIC ``backtrace`` from the
@@ -26,15 +29,16 @@ class BackTracerC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rif, x, v, h, ds):
         ctx.shape = rif.shape
-        ctx.rif = rif.detach().flatten()
         ctx.h, ctx.ds = h, ds
-        ctx.outx, ctx.outv = drrt.TracerC().trace(ctx.rif, ctx.shape, x.detach(), v.detach(), h, ds)
+        outx, outv = drrt.TracerC().trace(rif.detach().flatten(), ctx.shape, x.detach(), v.detach(), h, ds)
         ctx.order = drrt.last_order          # the adjoint visits rays in the forward's bundle order
-        return ctx.outx.clone(), ctx.outv.clone()
+        ctx.save_for_backward(rif, outx, outv)
+        return outx, outv
 
     @staticmethod
     def backward(ctx, grad_x, grad_v):
-        drif = drrt.TracerC().backtrace(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v,
+        rif, outx, outv = ctx.saved_tensors
+        drif = drrt.TracerC().backtrace(rif.detach().flatten(), ctx.shape, outx, outv, grad_x, grad_v,
                                         ctx.h, ctx.ds, order=ctx.order).reshape(*ctx.shape)
         return drif, None, None, None, None
 
@@ -45,21 +49,22 @@ class BackPlaneTracerC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rif, x, v, sp, sn, h, ds):
         ctx.shape = rif.shape
-        ctx.rif = rif.detach().flatten()
         ctx.h, ctx.ds = h, ds
-        ctx.outx, ctx.outv, outmask = drrt.TracerC().trace_pln(
-            ctx.rif, ctx.shape, x.detach(), v.detach(), sp.detach(), sn.detach(), h, ds)
+        outx, outv, outmask = drrt.TracerC().trace_pln(
+            rif.detach().flatten(), ctx.shape, x.detach(), v.detach(), sp.detach(), sn.detach(), h, ds)
         ctx.order = drrt.last_order
         outmask = outmask.to(torch.bool)
         ctx.mark_non_differentiable(outmask)
-        return ctx.outx.clone(), ctx.outv.clone(), outmask
+        ctx.save_for_backward(rif, outx, outv)
+        return outx, outv, outmask
 
     @staticmethod
     def backward(ctx, grad_x, grad_v, outmask):
+        rif, outx, outv = ctx.saved_tensors
         if outmask is not None and outmask.dtype == torch.bool:     # as written, :366-367
             grad_x = grad_x.clone()
             grad_x[outmask] = 0
-        drif = drrt.TracerC().backtrace(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v,
+        drif = drrt.TracerC().backtrace(rif.detach().flatten(), ctx.shape, outx, outv, grad_x, grad_v,
                                         ctx.h, ctx.ds, order=ctx.order).reshape(*ctx.shape)
         return drif, None, None, None, None, None, None
 
@@ -70,16 +75,17 @@ class BackTargetTracerC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rif, x, v, sp, h, ds):
         ctx.shape = rif.shape
-        ctx.rif = rif.detach().flatten()
         ctx.h, ctx.ds = h, ds
-        ctx.outx, ctx.outv, dist2 = drrt.TracerC().trace_target(
-            ctx.rif, ctx.shape, x.detach(), v.detach(), sp.detach(), h, ds)
+        outx, outv, dist2 = drrt.TracerC().trace_target(
+            rif.detach().flatten(), ctx.shape, x.detach(), v.detach(), sp.detach(), h, ds)
         ctx.order = drrt.last_order
-        return ctx.outx.clone(), ctx.outv.clone(), dist2
+        ctx.save_for_backward(rif, outx, outv)
+        return outx, outv, dist2
 
     @staticmethod
     def backward(ctx, grad_x, grad_v, outdist):
-        drif = drrt.TracerC().backtrace(ctx.rif, ctx.shape, ctx.outx, ctx.outv, grad_x, grad_v,
+        rif, outx, outv = ctx.saved_tensors
+        drif = drrt.TracerC().backtrace(rif.detach().flatten(), ctx.shape, outx, outv, grad_x, grad_v,
                                         ctx.h, ctx.ds, order=ctx.order).reshape(*ctx.shape)
         return drif, None, None, None, None, None
 
@@ -90,17 +96,17 @@ class BackSDFTracerC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rif, sdf, x, v, h, ds):
         ctx.shape = rif.shape
-        ctx.rif = rif.detach().flatten()
-        ctx.sdf = sdf.detach().flatten()
         ctx.h, ctx.ds = h, ds
-        ctx.outx, ctx.outv = drrt.TracerC().trace_sdf(ctx.rif, ctx.sdf, ctx.shape, x.detach(),
-                                                      v.detach(), h, ds)
+        outx, outv = drrt.TracerC().trace_sdf(rif.detach().flatten(), sdf.detach().flatten(), ctx.shape, x.detach(),
+                                              v.detach(), h, ds)
         ctx.order = drrt.last_order
-        return ctx.outx.clone(), ctx.outv.clone()
+        ctx.save_for_backward(rif, sdf, outx, outv)
+        return outx, outv
 
     @staticmethod
     def backward(ctx, grad_x, grad_v):
-        drif = drrt.TracerC().backtrace_sdf(ctx.rif, ctx.sdf, ctx.shape, ctx.outx, ctx.outv,
+        rif, sdf, outx, outv = ctx.saved_tensors
+        drif = drrt.TracerC().backtrace_sdf(rif.detach().flatten(), sdf.detach().flatten(), ctx.shape, outx, outv,
                                             grad_x, grad_v, ctx.h, ctx.ds, order=ctx.order).reshape(*ctx.shape)
         return drif, None, None, None, None, None
 
@@ -111,15 +117,16 @@ class BackCableTracerC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rif, radius, length, x, v, sp, ds):
         ctx.radius, ctx.length, ctx.ds = radius, length, ds
-        ctx.rif = rif.detach().flatten()
-        ctx.outx, ctx.outv, dist2 = drrt.TracerC().trace_cable(
-            ctx.rif, radius, length, x.detach(), v.detach(), sp.detach(), ds)
-        return ctx.outx.clone(), ctx.outv.clone(), dist2
+        outx, outv, dist2 = drrt.TracerC().trace_cable(
+            rif.detach().flatten(), radius, length, x.detach(), v.detach(), sp.detach(), ds)
+        ctx.save_for_backward(rif, outx, outv)
+        return outx, outv, dist2
 
     @staticmethod
     def backward(ctx, grad_x, grad_v, outdist):
-        drif = drrt.TracerC().backtrace_cable(ctx.rif, ctx.radius, ctx.length, ctx.outx, ctx.outv,
-                                              grad_x, grad_v, ctx.ds)
+        rif, outx, outv = ctx.saved_tensors
+        drif = drrt.TracerC().backtrace_cable(rif.detach().flatten(), ctx.radius, ctx.length, outx, outv,
+                                              grad_x, grad_v, ctx.ds).reshape(rif.shape)
         return drif, None, None, None, None, None, None
 
 

@@ -4,13 +4,26 @@ workload of BASELINE.json.
 
 One "step" = one forward march (drrt_trace_f32) + one adjoint march (drrt_backtrace_f32) over
 one batch of rays, inputs resident in HBM, called through the C ABI (ctypes) on torch's current
-stream.  With N > 1 ranks (torchrun, one process per GPU, backend nccl = RCCL) every rank marches
-its own batch of `--rays` rays (weak scaling) against a replicated grid and the per-rank dL/dn
-grids are summed by ONE all-reduce per step -- the path's only exchange.
+stream.
+
+Multi-GPU (one process per GPU, backend nccl = RCCL): the refractive-index grid is replicated, rays
+are sharded, and the per-rank dL/dn grids are summed by ONE all-reduce per step -- the path's only
+exchange.
+  * `python bench.py --gpus N` with no launcher starts the N ranks ITSELF (child processes, before
+    anything touches the GPU) and relays rank 0's JSON line; it exits non-zero when fewer than N
+    GPUs are visible (nccl) or when any rank fails -- it never falls back to fewer ranks;
+  * under `torch.distributed.run` (RANK / WORLD_SIZE in the environment) it runs as one rank and
+    refuses a WORLD_SIZE that differs from --gpus.
+  * `--scaling strong` (default): the metric's ONE 1M-ray set is split into contiguous shards
+    (dist.shard_bounds); value = global forward ray-steps / max-over-ranks time incl. the
+    all-reduce.  `--scaling weak`: every rank marches its own `--rays` rays.  `--scaling both`
+    (default for N > 1): value/ms_per_step are the strong figures, `weak_scaling` carries the weak.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      -- the dominant kernel (adjoint march): algorithmic bytes / launch duration,
-                   measured live with HIP events recorded around the kernel inside the library
+  roofline      -- the dominant kernel (adjoint march): SURVEY 8.6's algorithmic bytes / launch
+                   duration (HIP events recorded around the kernel inside the library) against the
+                   HBM peak, PLUS the bound that physically applies (`physical_bound`,
+                   `physical_frac`), derived from the committed PMC summary named in `pmc_source`
   roofline_fwd  -- same for the forward march kernel (the 40 %-of-HBM target of north_star)
   cpu_baseline  -- the CPU oracle (plain-C port of the reference, 1 thread) timed on a bounded
                    sample of the same workload (rank 0, N=1 only)
@@ -21,33 +34,128 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.29 TB/s measured copy
 B_FWD = 32.0                   # algorithmic bytes per forward ray-step: 8 fp32 taps
 B_ADJ = 64.0                   # adjoint: 8 taps read + 8 fp32 atomic adds
+# Committed rocprofv3 PMC summary (tools/profile_bench.sh + tools/condense_profile.py on THIS command) that
+# `roofline.traffic` and the physical-bound figures are read from.  It is NOT measured in the run: the
+# bench line says so in `traffic_source` / `pmc_source`.
+PMC_PROFILE = os.path.join("profiles", "r2_pmc.json")
+PMC_FALLBACK = os.path.join("profiles", "r1f_pmc.json")
+N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMDs
+CLK_HZ = 2.4e9                 # nominal shader clock (the chip may hold less under load; stated, not measured)
+VALU_CYCLES = 4.0              # a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU counts
+                               # exactly one quad-cycle per instruction on these kernels; tools/valu_bench.hip: 3.9)
+TA_LANES_PER_CLK_CU = 3.4      # texture-addresser rate of a pair gather, lanes per clock per CU (tools/gather_bench.hip:
+                               # 2.1e12 lane-addresses/s chip-wide with nothing else in the loop)
 
 
-def make_workload(R: int, n_rays: int, device, seed: int):
-    """Luneburg ball on an R^3 grid + jittered plane source on the y=0 face, v=(0,1,0)
-    (plane_source3_rand-equivalent, /root/reference/core/source.py:54-69: pixel (i,j) -> position
-    (x,0,z) with j (z) the fast index).  Rays are NOT pre-sorted."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--rays", type=int, default=1024 * 1024,
+                    help="rays of the GLOBAL set (strong scaling) / per GPU (weak scaling); a perfect square")
+    ap.add_argument("--scaling", choices=("strong", "weak", "both"), default=None,
+                    help="default: strong for --gpus 1, both for --gpus > 1")
+    ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--direct-atomics", action="store_true")
+    ap.add_argument("--lds-bricks", action="store_true", help="forward: opt-in LDS-staged grid bricks")
+    ap.add_argument("--no-order-reuse", action="store_true",
+                    help="adjoint computes its own visit order instead of reusing the forward's")
+    ap.add_argument("--quad", action="store_true", help="opt-in: build / use the 16-byte quad copy of the grid "
+                                                         "(DRRT_FLAG_QUAD_GRID; forward builds it, adjoint reuses it)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-counters", action="store_true", help="print LDS-window counters (stderr)")
+    ap.add_argument("--experiment", type=int, default=0, help="development ablation id (0 = product)")
+    ap.add_argument("--fwd-flags", type=lambda v: int(v, 0), default=0, help="extra DRRT_FLAG_* bits for the forward call")
+    ap.add_argument("--adj-flags", type=lambda v: int(v, 0), default=0, help="extra DRRT_FLAG_* bits for the adjoint call")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
+                                                        "to rehearse the multi-rank flow on a 1-GPU box)")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus == 1 else "both"
+    return args
+
+
+# ------------------------------------------------------------------------------------------------
+# self-launch: N child ranks, one GPU each, started BEFORE this process touches the GPU
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    import torch          # device_count() does not initialise the GPU on this image
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        print("bench.py: no GPU visible (there is no CPU path)", file=sys.stderr)
+        return 2
+    if args.backend == "nccl" and ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible; refusing to run fewer ranks "
+              f"(use --backend gloo to rehearse the multi-rank flow on shared GPUs)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):      # one rank failed: do not leave the others waiting
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    out0 = procs[0].stdout.read()      # one JSON line: far below the pipe buffer, safe to read after exit
+    lines = [l for l in out0.decode(errors="replace").splitlines() if l.startswith("{")]
+    if rc != 0 or not lines:
+        print(f"bench.py: a rank failed (exit codes {[p.returncode for p in procs]})", file=sys.stderr)
+        return rc or 1
+    d = json.loads(lines[-1])
+    if d.get("n_gpus") != args.gpus:
+        print(f"bench.py: ranks reported n_gpus={d.get('n_gpus')} != --gpus {args.gpus}", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+def make_grid(R: int, device):
+    import torch
     span = 1.0
-    h = span / (R - 1)
-    ds = h / 2                                  # step_res = 2 (core/luneburg_opt.py:38,48-49)
     g = torch.linspace(0.0, span, R, device=device)
     Z, Y, X = torch.meshgrid(g, g, g, indexing="ij")
     r = torch.sqrt((X - span / 2) ** 2 + (Y - span / 2) ** 2 + (Z - span / 2) ** 2) / (span / 2)
-    rif = torch.sqrt(2.0 - torch.clamp(r, max=1.0) ** 2).to(torch.float32).contiguous()
-    del X, Y, Z, r
+    return torch.sqrt(2.0 - torch.clamp(r, max=1.0) ** 2).to(torch.float32).contiguous()
+
+
+def make_rays(n_rays: int, seed: int):
+    """Jittered plane source on the y=0 face, v=(0,1,0) (plane_source3_rand-equivalent,
+    /root/reference/core/source.py:54-69: pixel (i,j) -> position (x,0,z) with j (z) the fast index).
+    Host tensors; rays are NOT pre-sorted."""
+    import torch
+    span = 1.0
     side = int(round(n_rays ** 0.5))
     assert side * side == n_rays, "--rays must be a perfect square (plane source pixels)"
     gen = torch.Generator(device="cpu").manual_seed(seed)
@@ -60,30 +168,69 @@ def make_workload(R: int, n_rays: int, device, seed: int):
     pos[:, 1] = 0.0
     vel = torch.zeros(n_rays, 3)
     vel[:, 1] = 1.0
-    return rif, pos.to(device), vel.to(device), h, ds
+    return pos, vel
 
 
-def measured_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel, from the newest committed rocprofv3 PMC summary
-    (profiles/*_pmc.json, produced by tools/profile_bench.sh + tools/condense_profile.py on the SAME
-    command: separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when no summary matches."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime)
-    for f in reversed(files):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        for k, v in d.items():
-            if k.startswith(kernel_prefix) and "hbm_traffic_bytes_per_launch" in v:
-                return {"bytes": v["hbm_traffic_bytes_per_launch"], "source": os.path.basename(f)}
+def make_workload(R: int, n_rays: int, device, seed: int):
+    """Luneburg ball on an R^3 grid + the plane source above (kept for tools/ and tests)."""
+    span = 1.0
+    h = span / (R - 1)
+    ds = h / 2                                  # step_res = 2 (core/luneburg_opt.py:38,48-49)
+    pos, vel = make_rays(n_rays, seed)
+    return make_grid(R, device), pos.to(device), vel.to(device), h, ds
+
+
+def load_pmc():
+    """The committed PMC summary (see PMC_PROFILE).  -> (dict, basename) or (None, None)."""
+    for rel in (PMC_PROFILE, PMC_FALLBACK):
+        f = os.path.join(ROOT, rel)
+        if os.path.exists(f):
+            try:
+                return json.load(open(f)), rel
+            except Exception:
+                continue
+    return None, None
+
+
+def pmc_kernel(pmc, prefix):
+    if not pmc:
+        return None
+    for k, v in pmc.items():
+        if k.startswith(prefix):
+            return v
     return None
+
+
+def physical_bound(pk, ms, lane_addresses):
+    """Which on-chip unit bounds a march kernel, from the PMC summary `pk` of the same command and the live kernel
+    time `ms`: VALU issue (instructions x 4 cycles per SIMD) vs the texture addresser (gather lane-addresses)."""
+    out = {}
+    if ms != ms or ms <= 0:
+        return out
+    cyc = ms * 1e-3 * CLK_HZ
+    ta = lane_addresses / (TA_LANES_PER_CLK_CU * 256 * cyc)
+    out["ta_gather_frac"] = ta
+    if pk and "SQ_INSTS_VALU" in pk:
+        valu = pk["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMD * cyc)
+        out["valu_issue_frac"] = valu
+        out["valu_insts_per_launch_pmc"] = pk["SQ_INSTS_VALU"]
+        if valu >= ta:
+            out["physical_bound"], out["physical_frac"] = "valu_issue", valu
+        else:
+            out["physical_bound"], out["physical_frac"] = "texture_addresser_gather", ta
+    else:
+        out["physical_bound"], out["physical_frac"] = "texture_addresser_gather", ta
+    out["physical_note"] = (f"taps are served by L1/L2/Infinity Cache (the 64 MiB grid is cache-resident), so HBM is not the "
+                            f"physical limiter; fractions assume the nominal {CLK_HZ / 1e9:.1f} GHz clock, VALU = "
+                            f"{VALU_CYCLES:.0f} cycles per wave64 instruction per SIMD, gather = {TA_LANES_PER_CLK_CU} "
+                            f"lane-addresses per clock per CU")
+    return out
 
 
 def cpu_baseline(R, h, ds, rif_np, pos_np, vel_np, target_seconds=15.0):
     """Time the CPU oracle (kind 'port': plain-C restatement of the reference, single thread --
     the reference's CPU path is single-threaded) on a ray sub-sample."""
+    import numpy as np
     from oracle import oracle as O
     O.build()
     n_probe = 512
@@ -118,27 +265,9 @@ def cpu_baseline(R, h, ds, rif_np, pos_np, vel_np, target_seconds=15.0):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", type=int, default=256)
-    ap.add_argument("--rays", type=int, default=1024 * 1024, help="rays per GPU (perfect square)")
-    ap.add_argument("--no-sort", action="store_true")
-    ap.add_argument("--direct-atomics", action="store_true")
-    ap.add_argument("--lds-bricks", action="store_true", help="forward: opt-in LDS-staged grid bricks")
-    ap.add_argument("--no-order-reuse", action="store_true",
-                    help="adjoint computes its own visit order instead of reusing the forward's")
-    ap.add_argument("--quad", action="store_true", help="opt-in: build / use the 16-byte quad copy of the grid "
-                                                         "(DRRT_FLAG_QUAD_GRID; forward builds it, adjoint reuses it)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--debug-counters", action="store_true", help="print LDS-window counters (stderr)")
-    ap.add_argument("--experiment", type=int, default=0, help="development ablation id (0 = product)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
-                                                        "to rehearse the multi-rank flow on a 1-GPU box)")
-    args = ap.parse_args()
+def run_rank(args) -> int:
+    import torch
+    import torch.distributed as dist
 
     # The contract is ONE JSON line on stdout.  RCCL / gloo print banners to the process's stdout from
     # native code (e.g. "RCCL version : ..."), so file descriptor 1 is pointed at stderr until the final
@@ -150,17 +279,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to benchmark a different rank count",
+              file=sys.stderr)
+        return 2
     ndev = torch.cuda.device_count()
     if ndev == 0:
-        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+        print("bench.py needs a GPU (there is no CPU path)", file=sys.stderr)
+        return 2
     if args.backend == "nccl" and world > ndev:
-        raise SystemExit(f"{world} ranks but only {ndev} GPUs visible")
+        print(f"bench.py: {world} ranks but only {ndev} GPUs visible", file=sys.stderr)
+        return 2
     local = local % ndev                         # gloo rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or "RANK" in os.environ          # under torchrun: also with a single rank (rehearses RCCL)
+    use_dist = world > 1 or "RANK" in os.environ          # under a launcher: also with a single rank (rehearses RCCL)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
@@ -168,116 +301,170 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            return 2
 
     from adjointnonlinearraytracing_amd import _lib
+    from adjointnonlinearraytracing_amd import dist as drrt_dist
     lib = _lib.load()            # loud failure if the HIP library is missing
 
     R = args.grid
-    rif, pos, vel, h, ds = make_workload(R, args.rays, dev, seed=rank)
-    n = pos.shape[0]
+    span = 1.0
+    h = span / (R - 1)
+    ds = h / 2                                   # step_res = 2 (core/luneburg_opt.py:38,48-49)
+    rif = make_grid(R, dev)
     nvox = rif.numel()
     res = (C.c_int * 3)(R, R, R)
     flags = 0 if args.no_sort else _lib.FLAG_SORT_RAYS
     if args.quad and not args.lds_bricks:
         flags |= _lib.FLAG_QUAD_GRID                   # forward builds the quad copy, the paired adjoint reuses it
-    fflags = flags | (_lib.FLAG_LDS_BRICKS if args.lds_bricks else 0)
-    aflags = flags | (_lib.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0)
+    fflags = flags | (_lib.FLAG_LDS_BRICKS if args.lds_bricks else 0) | args.fwd_flags
+    aflags = flags | (_lib.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | args.adj_flags
     if flags & _lib.FLAG_QUAD_GRID:
         aflags |= _lib.FLAG_QUAD_REUSE
     aflags |= (_lib.FLAG_DEBUG_COUNTERS if args.debug_counters else 0) | ((args.experiment & 0xff) << 8)
-    ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, nvox, flags)) + 1024, dtype=torch.uint8, device=dev)
-    xt, vt = torch.empty_like(pos), torch.empty_like(vel)
-    dx, dv = torch.ones_like(pos), torch.ones_like(vel)          # adjoint seed dx=dv=1 (src/test.cpp:142-144)
-    grad = torch.empty(nvox, dtype=torch.float32, device=dev)
-    st_f = torch.zeros(3, dtype=torch.int64, device=dev)
-    st_a = torch.zeros(3, dtype=torch.int64, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
-
-    def step():
-        _lib.check(lib.drrt_trace_f32(p(rif), nvox, res, n, p(pos), p(vel), h, ds, p(xt), p(vt),
-                                      p(st_f), p(ws), ws.numel(), fflags, stream))
-        if (flags & _lib.FLAG_SORT_RAYS) and not args.no_order_reuse:        # adjoint visits rays in the forward's bundle order
-            lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
-        _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),
-                                          p(st_a), p(ws), ws.numel(), aflags, stream))
-        if use_dist:
-            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+    grad = torch.empty(nvox, dtype=torch.float32, device=dev)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    _lib.check(lib.drrt_profile_begin(8 * args.steps + 8))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = _lib.profile_collect()
-    lib.drrt_profile_end()
+    def run_mode(mode):
+        """-> dict of this rank's measurements for one scaling mode."""
+        if mode == "strong":
+            gpos, gvel = make_rays(args.rays, seed=0)              # the metric's single ray set, same on every rank
+            lo, hi = drrt_dist.shard_bounds(args.rays, rank, world)
+            pos, vel = gpos[lo:hi].contiguous().to(dev), gvel[lo:hi].contiguous().to(dev)
+        else:
+            pos, vel = (t.to(dev) for t in make_rays(args.rays, seed=rank))
+        n = pos.shape[0]
+        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, nvox, flags)) + 1024, dtype=torch.uint8, device=dev)
+        xt, vt = torch.empty_like(pos), torch.empty_like(vel)
+        dx, dv = torch.ones_like(pos), torch.ones_like(vel)          # adjoint seed dx=dv=1 (src/test.cpp:142-144)
+        st_f = torch.zeros(3, dtype=torch.int64, device=dev)
+        st_a = torch.zeros(3, dtype=torch.int64, device=dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    if args.debug_counters:
-        off = (ws.numel() - 512) & ~7
-        dbg = ws[off:off + 512].view(torch.int64).cpu().tolist()
-        print(f"[debug] window flushes {dbg[0]}, ray-steps via LDS window {dbg[1]}, via global fallback {dbg[2]}",
-              file=sys.stderr)
-    fwd_steps = int(st_f[0].item()); adj_steps = int(st_a[0].item())
-    n_failed = int(st_f[1].item())
-    t = torch.tensor([elapsed, float(fwd_steps), float(adj_steps)], dtype=torch.float64, device=dev)
-    if use_dist:
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0]); fwd_total = float(tsum[1]); adj_total = float(tsum[2])
-    else:
-        fwd_total, adj_total = float(fwd_steps), float(adj_steps)
+        def step(k=None):
+            _lib.check(lib.drrt_trace_f32(p(rif), nvox, res, n, p(pos), p(vel), h, ds, p(xt), p(vt),
+                                          p(st_f), p(ws), ws.numel(), fflags, stream))
+            if (flags & _lib.FLAG_SORT_RAYS) and not args.no_order_reuse:    # adjoint visits rays in the forward's bundle order
+                lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
+            _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),
+                                              p(st_a), p(ws), ws.numel(), aflags, stream))
+            if use_dist:
+                if k is not None:
+                    ev[k][0].record()
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                if k is not None:
+                    ev[k][1].record()
 
-    if rank == 0:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        _lib.check(lib.drrt_profile_begin(8 * args.steps + 8))
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = _lib.profile_collect()
+        lib.drrt_profile_end()
+        ms_ar = (sum(a.elapsed_time(b) for a, b in ev) / len(ev)) if use_dist else 0.0
+
+        if args.debug_counters:
+            off = (ws.numel() - 512) & ~7
+            dbg = ws[off:off + 512].view(torch.int64).cpu().tolist()
+            print(f"[debug] window flushes {dbg[0]}, ray-steps via LDS window {dbg[1]}, via global fallback {dbg[2]}",
+                  file=sys.stderr)
+        fwd_steps = int(st_f[0].item()); adj_steps = int(st_a[0].item())
+        n_failed = int(st_f[1].item())
+        t = torch.tensor([elapsed, float(fwd_steps), float(adj_steps)], dtype=torch.float64, device=dev)
+        if use_dist:
+            tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            elapsed = float(tmax[0]); fwd_total = float(tsum[1]); adj_total = float(tsum[2])
+        else:
+            fwd_total, adj_total = float(fwd_steps), float(adj_steps)
+
         def avg(name):
             v = [ms for k, ms in prof if k == name]
             return (sum(v) / len(v)) if v else float("nan")
-        ms_fwd, ms_adj, ms_sort, ms_zero = avg("trace"), avg("backtrace"), avg("sort"), avg("zero")
-        ms_quad = avg("quad")
+        return dict(mode=mode, n=n, elapsed=elapsed, fwd_total=fwd_total, adj_total=adj_total, fwd_steps=fwd_steps,
+                    adj_steps=adj_steps, n_failed=n_failed, ms_fwd=avg("trace"), ms_adj=avg("backtrace"),
+                    ms_sort=avg("sort"), ms_zero=avg("zero"), ms_quad=avg("quad"), ms_allreduce=ms_ar,
+                    pos=pos, vel=vel)
+
+    modes = ["strong", "weak"] if args.scaling == "both" else [args.scaling]
+    results = {m: run_mode(m) for m in modes}
+    main_mode = modes[0]
+    m = results[main_mode]
+
+    if rank == 0:
+        n, fwd_steps, adj_steps = m["n"], m["fwd_steps"], m["adj_steps"]
+        ms_fwd, ms_adj = m["ms_fwd"], m["ms_adj"]
         ach_adj = adj_steps * B_ADJ / (ms_adj * 1e-3) / 1e9
         ach_fwd = fwd_steps * B_FWD / (ms_fwd * 1e-3) / 1e9
-        default_cfg = (R == 256 and n == 1024 * 1024 and not args.no_sort and not args.direct_atomics
-                       and not args.experiment and not args.quad and not args.lds_bricks)
-        tr_adj = measured_traffic("drrt::k_backtrace_win") if default_cfg else None
-        tr_fwd = measured_traffic("drrt::k_trace") if default_cfg else None
+        default_cfg = (R == 256 and n == 1024 * 1024 and world == 1 and not args.no_sort and not args.direct_atomics
+                       and not args.experiment and not args.quad and not args.lds_bricks and not args.fwd_flags
+                       and not args.adj_flags)
+        pmc, pmc_src = load_pmc() if default_cfg else (None, None)
+        pk_adj, pk_fwd = pmc_kernel(pmc, "drrt::k_backtrace_win"), pmc_kernel(pmc, "drrt::k_trace<0>")
+        tr_adj = pk_adj and pk_adj.get("hbm_traffic_bytes_per_launch")
+        tr_fwd = pk_fwd and pk_fwd.get("hbm_traffic_bytes_per_launch")
+        src_note = (f"{pmc_src}: rocprofv3 --pmc passes of this command, committed; read from that file, NOT "
+                    f"measured in this run") if pmc_src else None
+        shard = (f"the metric's single set of {args.rays} rays split into {world} contiguous shards "
+                 f"({n} on rank 0)") if main_mode == "strong" else f"{n} rays per GPU (own seed per rank)"
+        roof = {"bound": "hbm", "kernel": "adjoint march (k_backtrace_win)", "achieved": ach_adj,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_adj / HBM_PEAK_GBS, "traffic": tr_adj,
+                "traffic_source": src_note, "pmc_source": pmc_src,
+                "hbm_measured_gbps": (tr_adj / (ms_adj * 1e-3) / 1e9) if tr_adj else None,
+                "algorithmic_bytes_per_ray_step": B_ADJ, "ray_steps_per_launch": adj_steps, "avg_kernel_ms": ms_adj}
+        roof.update(physical_bound(pk_adj, ms_adj, 4.0 * adj_steps))
+        roof_f = {"bound": "hbm", "kernel": "forward march (k_trace)", "achieved": ach_fwd,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_fwd / HBM_PEAK_GBS, "traffic": tr_fwd,
+                  "traffic_source": src_note, "pmc_source": pmc_src,
+                  "hbm_measured_gbps": (tr_fwd / (ms_fwd * 1e-3) / 1e9) if tr_fwd else None,
+                  "algorithmic_bytes_per_ray_step": B_FWD, "ray_steps_per_launch": fwd_steps, "avg_kernel_ms": ms_fwd,
+                  "note": "frac can exceed 1: SURVEY 8.6 counts every tap as an HBM read, but the taps are cache-served"}
+        roof_f.update(physical_bound(pk_fwd, ms_fwd, 4.0 * fwd_steps))
         out = {
             "metric": "ray-steps/sec (fwd+adjoint), 256^3 RIF grid, 1M rays x 512 steps",
-            "value": fwd_total * args.steps / elapsed,
+            "value": m["fwd_total"] * args.steps / m["elapsed"],
             "unit": "ray-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": m["elapsed"] / args.steps * 1e3,
+            "higher_is_better": True, "scaling": main_mode, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Luneburg ball {R}^3 fp32 grid (replicated), {n} rays per GPU from a seeded jittered "
+            "config": {"workload": f"Luneburg ball {R}^3 fp32 grid (replicated), {shard} from a seeded jittered "
                                    f"plane source on the y=0 face, ds=h/2, fwd trace + adjoint backtrace (dx=dv=1)"
-                                   + (", one RCCL all-reduce(sum) of the grid per step" if world > 1 else ""),
-                       "grid": R, "rays_per_gpu": n, "fwd_ray_steps_per_gpu": fwd_steps,
-                       "adj_ray_steps_per_gpu": adj_steps, "n_failed": n_failed,
-                       "sort_rays": not args.no_sort, "quad_grid": bool(flags & _lib.FLAG_QUAD_GRID), "parallelism": f"ray-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "adjoint march (k_backtrace)", "achieved": ach_adj,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_adj / HBM_PEAK_GBS, "traffic": tr_adj and tr_adj["bytes"],
-                         "traffic_source": tr_adj and tr_adj["source"],
-                         "algorithmic_bytes_per_ray_step": B_ADJ, "ray_steps_per_launch": adj_steps,
-                         "avg_kernel_ms": ms_adj},
-            "roofline_fwd": {"bound": "hbm", "kernel": "forward march (k_trace)", "achieved": ach_fwd,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_fwd / HBM_PEAK_GBS, "traffic": tr_fwd and tr_fwd["bytes"],
-                             "traffic_source": tr_fwd and tr_fwd["source"],
-                             "algorithmic_bytes_per_ray_step": B_FWD, "ray_steps_per_launch": fwd_steps,
-                             "avg_kernel_ms": ms_fwd},
-            "phase_ms": {"sort_avg": ms_sort, "zero_grid": ms_zero, "quad_copy": None if ms_quad != ms_quad else ms_quad,
-                         "trace": ms_fwd, "backtrace": ms_adj},
+                                   + (", one all-reduce(sum) of the dL/dn grid per step "
+                                      f"(backend {args.backend})" if use_dist else ""),
+                       "grid": R, "global_rays": int(args.rays if main_mode == "strong" else args.rays * world),
+                       "rays_rank0": n, "fwd_ray_steps_rank0": fwd_steps, "adj_ray_steps_rank0": adj_steps,
+                       "fwd_ray_steps_global": m["fwd_total"], "n_failed": m["n_failed"],
+                       "sort_rays": not args.no_sort, "quad_grid": bool(flags & _lib.FLAG_QUAD_GRID),
+                       "parallelism": f"ray-shard x{world}", "backend": args.backend if use_dist else None},
+            "roofline": roof,
+            "roofline_fwd": roof_f,
+            "phase_ms": {"sort_avg": m["ms_sort"], "zero_grid": m["ms_zero"],
+                         "quad_copy": None if m["ms_quad"] != m["ms_quad"] else m["ms_quad"],
+                         "trace": ms_fwd, "backtrace": ms_adj, "allreduce": m["ms_allreduce"] if use_dist else None},
             "fwd_only_ray_steps_per_s_per_gpu": fwd_steps / (ms_fwd * 1e-3),
         }
+        if "weak" in results and main_mode != "weak":
+            w = results["weak"]
+            out["weak_scaling"] = {"value": w["fwd_total"] * args.steps / w["elapsed"], "unit": "ray-steps/s",
+                                   "ms_per_step": w["elapsed"] / args.steps * 1e3, "rays_per_gpu": w["n"],
+                                   "phase_ms": {"sort_avg": w["ms_sort"], "trace": w["ms_fwd"], "backtrace": w["ms_adj"],
+                                                "allreduce": w["ms_allreduce"] if use_dist else None}}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(R, h, ds, rif.cpu().numpy(), pos.cpu().numpy(), vel.cpu().numpy(),
+            out["cpu_baseline"] = cpu_baseline(R, h, ds, rif.cpu().numpy(), m["pos"].cpu().numpy(), m["vel"].cpu().numpy(),
                                                target_seconds=args.cpu_seconds)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
@@ -285,6 +472,14 @@ def main():
         os.dup2(2, 1)
     if use_dist:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

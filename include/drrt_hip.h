@@ -86,8 +86,11 @@ extern "C" {
  *   h, ds     positive and finite
  * Non-finite ray components are tolerated: such rays march until max_steps and do not affect other rays'
  * forward results (their adjoint contributions are non-finite, as in any IEEE implementation).
- * Thread-safety: the visit-order hand-over (drrt_last_order / drrt_set_order_hint) and the profiling aid are
- * process-global; use the library from one host thread per process (one process per GPU).            */
+ * Thread-safety: the visit-order hand-over (drrt_last_order / drrt_set_order_hint) and drrt_last_error() are
+ * PER HOST THREAD (thread_local): a hint set on one thread is only seen by march calls of that thread.  The
+ * profiling aid (drrt_profile_*) is process-global and not thread-safe.  trace_pln / trace_sdf called with
+ * stats == NULL use one library-owned 24-byte stats block per device, shared by all streams of that device:
+ * pass your own stats block when running them concurrently on several streams of one device.        */
 
 typedef struct drrt_stats {
   unsigned long long ray_steps;  /* sum over rays of march iterations executed while the ray was live */
@@ -108,18 +111,26 @@ DRRT_API const char* drrt_last_error(void);
 /* Library / build identification, e.g. "drrt_hip 0.1 gfx950". */
 DRRT_API const char* drrt_version(void);
 
-/* ---- visit order hand-over (optimisation hint; results never depend on it) -------------------
+/* ---- visit order hand-over (optimisation hint; with a valid permutation results do not depend on it) ---
  * A sorted call (DRRT_FLAG_SORT_RAYS) leaves the permutation it used -- n uint32 ray indices, in
  * visit order -- inside the caller's workspace; drrt_last_order() returns that device pointer
  * (valid until the workspace is overwritten) and its length.
  * drrt_set_order_hint(order, n) makes the NEXT march call on this host thread visit its rays in
- * `order` instead of sorting (consumed by that call; ignored if its ray count differs).
+ * `order` instead of sorting.  That call consumes the hint as its first action -- also when it then fails
+ * validation or ignores the hint -- so a hint never outlives one call.  It is ignored when its ray count
+ * differs, by drrt_trace_target_f32 (whose state buffer would overlay an order living in the same workspace)
+ * and by the cable calls.  `order` must stay valid and unmodified until the call's kernels have finished;
+ * entries are range-checked on the device: an entry >= n leaves that slot's ray unvisited (its outputs
+ * unwritten) but is never dereferenced.  With a valid permutation results do not depend on the hint.
  * Intended pairing: the adjoint of a forward march (core/tracer.py:294-335 couples them through
  * ctx.outx/ctx.outv) reuses the forward's order -- rays that entered the grid together stay
  * together through any smooth medium, which keeps each wave inside its LDS gradient window even
  * where the exit rays alone (a focus, a caustic) say nothing about the bundle they came from.   */
 DRRT_API const uint32_t* drrt_last_order(size_t* n_out);
 DRRT_API void drrt_set_order_hint(const uint32_t* order, size_t n);
+/* Length of the hint currently armed on this host thread (0 = none): lets a binding assert that no hint
+ * survives a call. */
+DRRT_API size_t drrt_order_hint_pending(void);
 
 /* ---- forward marches ------------------------------------------------------------------- */
 

@@ -95,3 +95,46 @@ def test_tracerc_refuses_cpu_tensors_without_gpu(lib):
     from adjointnonlinearraytracing_amd import drrt
     with pytest.raises(RuntimeError, match="cuda"):
         drrt.TracerC().trace(torch.ones(4, 4, 4), (4, 4, 4), torch.zeros(2, 3), torch.zeros(2, 3), 1.0, 0.5)
+
+
+def test_order_hint_never_outlives_one_call(lib):
+    """a march call that fails validation must still consume the visit-order hint, so that a stale
+    device pointer cannot be picked up by a later call with the same ray count.  Validation failures happen
+    before any HIP call, so this runs without a GPU (null data pointers are never dereferenced)."""
+    import ctypes as C
+    h = lib.load()
+    res_bad = (C.c_int * 3)(4, 4, 5)            # 4*4*5 != nvox = 64 -> "Resolution doesn't match data"
+    res_ok = (C.c_int * 3)(4, 4, 4)
+    fake = C.c_void_p(0xDEAD0000)
+    one = C.c_void_p(0x1000)                    # non-null stand-in for rif (make_vol only checks for null)
+    n = 128
+
+    def armed():
+        h.drrt_set_order_hint(fake, n)
+        assert h.drrt_order_hint_pending() == n
+
+    calls = [
+        lambda: h.drrt_trace_f32(one, 64, res_bad, n, None, None, 1.0, 0.5, None, None, None, None, 0, 0, None),
+        lambda: h.drrt_trace_f16io(one, 64, res_bad, n, None, None, 1.0, 0.5, None, None, None, None, 0, 0, None),
+        lambda: h.drrt_trace_pln_f32(one, 64, res_bad, n, None, None, None, None, 1.0, 0.5, None, None, None,
+                                     None, None, 0, 0, None),
+        lambda: h.drrt_trace_sdf_f32(one, one, 64, res_bad, n, None, None, 1.0, 0.5, None, None, None, None, 0, 0, None),
+        lambda: h.drrt_trace_target_f32(one, 64, res_bad, n, None, None, None, 1.0, 0.5, None, None, None, None,
+                                        None, 0, 0, None),
+        lambda: h.drrt_backtrace_f32(one, 64, res_bad, n, None, None, None, None, 1.0, 0.5, None, None, None, 0, 0, None),
+        lambda: h.drrt_backtrace_f16io(one, 64, res_bad, n, None, None, None, None, 1.0, 0.5, None, None, None, 0, 0, None),
+        lambda: h.drrt_backtrace_sdf_f32(one, one, 64, res_bad, n, None, None, None, None, 1.0, 0.5, None, None,
+                                         None, 0, 0, None),
+        # valid grid, invalid step: fails in check_steps, after make_vol
+        lambda: h.drrt_trace_f32(one, 64, res_ok, n, None, None, 1.0, -0.5, None, None, None, None, 0, 0, None),
+        # cable calls: rres < 2
+        lambda: h.drrt_trace_cable_f32(one, 1, 1.0, 1.0, n, None, None, None, 0.1, None, None, None, None, None, 0, 0, None),
+        lambda: h.drrt_backtrace_cable_f32(one, 1, 1.0, 1.0, n, None, None, None, None, 0.1, one, None, None, 0, 0, None),
+    ]
+    for call in calls:
+        armed()
+        assert call() < 0 and h.drrt_last_error()
+        assert h.drrt_order_hint_pending() == 0
+    h.drrt_set_order_hint(fake, n)
+    h.drrt_set_order_hint(None, n)              # a null order disarms whatever n says
+    assert h.drrt_order_hint_pending() == 0

@@ -1,7 +1,8 @@
 """CPU tier: the ray-sharded multi-process path (adjointnonlinearraytracing_amd/dist.py) with
 world_size 2 over gloo.  The per-rank march is injected (the CPU oracle stands in for the HIP
-kernels, which need a GPU); what is under test is the sharding and the single all-reduce:
-every rank must end up with the gradient of the GLOBAL ray set."""
+kernels, which need a GPU); what is under test is the sharding, the hand-over of the forward's visit
+order to the adjoint, and the single all-reduce: every rank must end up with the gradient of the GLOBAL
+ray set."""
 import os
 import sys
 
@@ -17,15 +18,27 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _oracle_trace(rif_flat, shape, x, v, h, ds):
+    """Stand-in for the HIP forward: also returns a visit order (here: a fixed permutation of the shard), as
+    dist._hip_trace does, so that the order hand-over to the adjoint is under test."""
     from oracle import oracle as O
     o = O.trace(rif_flat.numpy(), tuple(shape), x.numpy(), v.numpy(), h, ds, dtype=np.float32)
-    return torch.from_numpy(o["xt"]), torch.from_numpy(o["vt"])
+    order = torch.arange(x.shape[0] - 1, -1, -1, dtype=torch.int32)
+    return torch.from_numpy(o["xt"]), torch.from_numpy(o["vt"]), order
 
 
-def _oracle_backtrace(rif_flat, shape, xt, vt, gx, gv, h, ds):
+_seen_orders = []
+
+
+def _oracle_backtrace(rif_flat, shape, xt, vt, gx, gv, h, ds, order=None):
+    """Stand-in for the HIP adjoint: visits the rays in `order` (the sum must not depend on it) and records that
+    it received the forward's order."""
     from oracle import oracle as O
-    b = O.backtrace(rif_flat.numpy(), tuple(shape), xt.numpy(), vt.numpy(), gx.numpy(), gv.numpy(), h, ds,
-                    dtype=np.float32)
+    assert order is not None and order.dtype == torch.int32 and order.numel() == xt.shape[0], \
+        "ShardedBackTracerC dropped the forward's visit order"
+    _seen_orders.append(order)
+    idx = order.long().numpy()
+    b = O.backtrace(rif_flat.numpy(), tuple(shape), xt.numpy()[idx], vt.numpy()[idx], gx.numpy()[idx], gv.numpy()[idx],
+                    h, ds, dtype=np.float32)
     return torch.from_numpy(b["grad"])
 
 
@@ -45,6 +58,7 @@ def _worker(rank, world, port, out_dir):
     xt, vt = D.ShardedBackTracerC.apply(rif, x, v, h, ds, None, _oracle_trace, _oracle_backtrace)
     loss = (xt ** 2).sum() + vt.sum()                          # ray-separable loss (core/luneburg_opt.py:102)
     loss.backward()
+    assert len(_seen_orders) == 1 and _seen_orders[0].numel() == x.shape[0]     # the adjoint got this shard's order
     tot = loss.detach().clone(); dist.all_reduce(tot)
     np.save(os.path.join(out_dir, f"grad_{rank}.npy"), rif.grad.numpy())
     np.save(os.path.join(out_dir, f"loss_{rank}.npy"), tot.numpy())

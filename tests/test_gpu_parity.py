@@ -582,3 +582,121 @@ def test_calls_follow_the_current_torch_stream(gpu, drrt_mod):
     side.synchronize()
     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
     assert cases.rel_l2(g.cpu().numpy(), gref.cpu().numpy()) <= 2e-6
+
+
+def test_order_hint_lifetime_and_range_check(gpu, drrt_mod):
+    """ADVICE r1 (order hint): (i) a call that fails validation consumes the hint -- the next successful call with
+    the same n sorts for itself and is correct; (ii) a hint with out-of-range entries cannot make the kernels
+    touch memory outside the ray arrays: those slots stay unvisited, every valid slot gets its exact result;
+    (iii) trace_target ignores the hint (its state buffer would overlay an order living in the workspace)."""
+    import ctypes as C
+    from adjointnonlinearraytracing_amd import _lib
+    lib = _lib.load()
+    R, span, n = 33, 1.0, 3000
+    h = span / (R - 1); ds = h / 2
+    rif = _t(cases.luneburg(R), gpu)
+    pos, vel = cases.cube_rays(n // 6, span, ds, seed=5)
+    n = len(pos)
+    pos_t, vel_t = _t(pos, gpu), _t(vel, gpu)
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = True
+    xt0, vt0 = T.trace(rif, rif.shape, pos_t, vel_t, h, ds)
+    dx = torch.ones_like(xt0); dv = torch.full_like(xt0, 0.1)
+    g0 = T.backtrace(rif, rif.shape, xt0, vt0, dx, dv, h, ds)
+    # (i) arm a hint full of garbage, fail a call, then run the same-n call: must match the unhinted result
+    garbage = torch.full((n,), 0x7FFFFFF0, dtype=torch.int32, device=gpu)
+    lib.drrt_set_order_hint(C.c_void_p(garbage.data_ptr()), n)
+    with pytest.raises(RuntimeError, match="Resolution doesn't match data"):
+        T.trace(rif, (R, R, R + 1), pos_t, vel_t, h, ds)
+    assert lib.drrt_order_hint_pending() == 0
+    xt1, vt1 = T.trace(rif, rif.shape, pos_t, vel_t, h, ds)
+    assert torch.equal(xt1, xt0) and torch.equal(vt1, vt0)
+    # (ii) a permutation with some entries replaced by out-of-range indices
+    perm = torch.randperm(n, device=gpu).to(torch.int32)
+    bad = perm.clone()
+    hole = torch.arange(0, n, 7, device=gpu)
+    bad[hole] = n + 12345
+    skipped = perm[hole].long()
+    xt2 = torch.full_like(xt0, -7.0); vt2 = torch.full_like(vt0, -7.0)
+    st = torch.zeros(3, dtype=torch.int64, device=gpu)
+    ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, rif.numel(), 1)), dtype=torch.uint8, device=gpu)
+    res = (C.c_int * 3)(R, R, R)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    lib.drrt_set_order_hint(p(bad), n)
+    _lib.check(lib.drrt_trace_f32(p(rif), rif.numel(), res, n, p(pos_t), p(vel_t), h, ds, p(xt2), p(vt2), p(st),
+                                  p(ws), ws.numel(), 1, None))
+    torch.cuda.synchronize()
+    keep = torch.ones(n, dtype=torch.bool, device=gpu); keep[skipped] = False
+    assert torch.equal(xt2[keep], xt0[keep]) and torch.equal(vt2[keep], vt0[keep])
+    assert bool((xt2[~keep] == -7.0).all())
+    g2 = torch.empty_like(g0)
+    lib.drrt_set_order_hint(p(bad), n)
+    _lib.check(lib.drrt_backtrace_f32(p(rif), rif.numel(), res, n, p(xt0), p(vt0), p(dx), p(dv), h, ds, p(g2), p(st),
+                                      p(ws), ws.numel(), 1, None))
+    dxk = dx.clone(); dvk = dv.clone()
+    # reference: the same adjoint over the kept rays only (skipped rays moved out of the box so they contribute nothing)
+    xt_far = xt0.clone(); xt_far[~keep] = -50.0
+    vt_far = vt0.clone(); vt_far[~keep] = torch.tensor([1.0, 0.0, 0.0], device=gpu)
+    g_ref = T.backtrace(rif, rif.shape, xt_far, vt_far, dxk, dvk, h, ds)
+    assert cases.rel_l2(g2.cpu().numpy(), g_ref.cpu().numpy()) <= 2e-5
+    # (iii) trace_target with a hint pointing INTO the workspace region its state buffer overwrites
+    tg = _t(np.tile(np.array([[0.5, 1.3, 0.5]], np.float32), (n, 1)), gpu)
+    a = T.trace_target(rif, rif.shape, pos_t, vel_t, tg, h, ds)
+    order = drrt_mod.last_order
+    assert order is not None
+    cnt = C.c_size_t(0)
+    inws = lib.drrt_last_order(C.byref(cnt))
+    lib.drrt_set_order_hint(C.c_void_p(inws), n)
+    b = T.trace_target(rif, rif.shape, pos_t, vel_t, tg, h, ds)
+    assert all(torch.equal(u, w) for u, w in zip(a, b))
+
+
+def test_bricks_plane_second_pass_matches_default(gpu, oracle, drrt_mod):
+    """with DRRT_FLAG_LDS_BRICKS trace_pln must flag the rays that can record a LATER exit
+    (start past the plane, head back through it) exactly like the default kernel, so that the second pass
+    re-marches them: compare both kernels with the oracle on such rays."""
+    R, span = 17, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif = cases.smooth_field(R, seed=9)
+    rng = np.random.default_rng(3)
+    n = 600
+    pos = (rng.random((n, 3)) * 0.9 + 0.05).astype(np.float32) * span
+    pos[:, 1] = 0.8 + 0.15 * rng.random(n).astype(np.float32)          # start PAST the plane y = 0.6 ...
+    vel = rng.normal(size=(n, 3)).astype(np.float32) * 0.3
+    vel[:, 1] = -np.abs(vel[:, 1]) - 0.7                                # ... heading back through it
+    vel /= np.linalg.norm(vel, axis=1, keepdims=True)
+    po = np.tile(np.array([[0.5, 0.6, 0.5]], np.float32) * span, (n, 1))
+    pd = np.tile(np.array([[0, 1, 0]], np.float32), (n, 1))
+    with oracle.arith("factored"):
+        ref = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float32, mode="plane", pln_o=po, pln_d=pd)
+    T = drrt_mod.TracerC()
+    for sort in (False, True):
+        drrt_mod.options.sort_rays = sort
+        for bricks in (False, True):
+            drrt_mod.options.lds_bricks = bricks
+            try:
+                xt, vt, fm = T.trace_pln(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), _t(po, gpu), _t(pd, gpu), h, ds)
+            finally:
+                drrt_mod.options.lds_bricks = False
+            assert np.array_equal(xt.cpu().numpy(), ref["xt"]) and np.array_equal(vt.cpu().numpy(), ref["vt"]), (sort, bricks)
+            assert np.array_equal(fm.cpu().numpy().astype(bool), ref["failmask"]), (sort, bricks)
+    drrt_mod.options.sort_rays = True
+
+
+def test_failed_ray_warning_is_asynchronous_but_not_lost(gpu, drrt_mod, capsys):
+    """src/tracer.cpp:89-90 prints "failed to exit all rays" when a ray is still live after max_steps.  The mirror
+    prints the same line without a host sync per call: it may appear late, never get lost."""
+    T = drrt_mod.TracerC()
+    rif = torch.ones(8, 8, 8, device=gpu)
+    pos = torch.tensor([[3.0, 3.0, 3.0], [3.0, 3.0, 3.0]], device=gpu)
+    vel = torch.tensor([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0]], device=gpu)      # ray 0 is at rest: it can never exit
+    drrt_mod.options.check_failed = True
+    try:
+        T.trace(rif, rif.shape, pos, vel, 1.0, 0.5)
+        drrt_mod.flush_warnings()
+        assert capsys.readouterr().out.count("failed to exit all rays") == 1
+        T.trace(rif, rif.shape, pos[1:], vel[1:], 1.0, 0.5)                 # every ray exits: silent
+        drrt_mod.flush_warnings()
+        assert "failed" not in capsys.readouterr().out
+    finally:
+        drrt_mod.options.check_failed = False
