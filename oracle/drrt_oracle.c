@@ -21,6 +21,26 @@
 #include <string.h>
 #include <stddef.h>
 
+#define EXPORT __attribute__((visibility("default")))
+
+/* ---- optional per-ray trajectory signature of the adjoint march (tests only) --------------------
+ * When a sink is set, backtrace (literal and factored, f32 and f64) folds the integer cell
+ * (floor(p/h) per axis) of every CONTRIBUTING step of ray i into sig[i] (FNV-1a) and counts the steps
+ * in nsteps[i].  Two arithmetics that give a ray the same signature walked it through the same cells in
+ * the same number of steps: that is how tests separate "tie" rays (a sample within rounding of a cell
+ * face lands in different cells under fp32 and fp64) from the rest.                        */
+static unsigned long long* g_sig = NULL;
+static int* g_sig_steps = NULL;
+static inline void sig_visit(size_t i, int ix, int iy, int iz) {
+  if (!g_sig) return;
+  unsigned long long h = g_sig[i] ? g_sig[i] : 1469598103934665603ULL;
+  const unsigned long long k = ((unsigned long long)(unsigned)ix << 42) ^ ((unsigned long long)(unsigned)iy << 21) ^
+                               (unsigned long long)(unsigned)iz;
+  h = (h ^ k) * 1099511628211ULL;
+  g_sig[i] = h ? h : 1;
+  g_sig_steps[i] += 1;
+}
+
 /* ---- float instantiation ---------------------------------------------------------- */
 #define REAL float
 #define FN(name) name##_f32
@@ -49,10 +69,9 @@
 #undef FMA
 #undef CYL_EPS
 
-#define EXPORT __attribute__((visibility("default")))
-
 /* arithmetic mode: 0 = literal (the reference's expression order), 1 = factored (the explicit
  * IEEE sequence the HIP kernels implement; see the second half of drrt_oracle_impl.h) */
+EXPORT void oracle_set_trajectory_sink(unsigned long long* sig, int* nsteps) { g_sig = sig; g_sig_steps = nsteps; }
 static int g_arith = 0;
 EXPORT void oracle_set_arith(int mode) { g_arith = mode ? 1 : 0; }
 EXPORT int oracle_get_arith(void) { return g_arith; }

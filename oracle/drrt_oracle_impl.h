@@ -57,6 +57,13 @@ static inline void FN(locate)(const int res[3], REAL h, const REAL p[3], FN(cell
   }
 }
 
+/* trajectory signature hook (tests only, see drrt_oracle.c): the floor cell of p, computed like locate() */
+static inline void FN(sig_cell)(size_t i, REAL h, const REAL p[3]) {
+  if (!g_sig) return;
+  const REAL rh = (REAL)1 / h;
+  sig_visit(i, (int)FLOOR(p[0] * rh), (int)FLOOR(p[1] * rh), (int)FLOOR(p[2] * rh));
+}
+
 /* ---- volume::eval_grad  (src/volume.cpp:101-181) --------------------------------- */
 static inline void FN(vol_eval_grad)(const REAL* data, const int res[3], REAL h,
                                      const REAL p[3], int mask, REAL* n, REAL g[3]) {
@@ -349,6 +356,7 @@ static int FN(backtrace_generic)(int use_sdf, const REAL* rif, const REAL* sdf, 
       }
       if (!active[i]) continue;
       any_active = 1; ++steps;
+      FN(sig_cell)(i, h, xi);
       REAL dn = mi[0]*g[0] + mi[1]*g[1] + mi[2]*g[2];                           /* :430 */
       REAL dnx[3] = { n*mi[0]*ds, n*mi[1]*ds, n*mi[2]*ds };                     /* :431-432 */
       FN(vol_splat)(grad, res, h, xi, dn*ds, dnx, 1, grad_scale);               /* :432 */
@@ -756,6 +764,7 @@ static int FN(backtrace_fact)(int use_sdf, const REAL* rif, const REAL* sdf, con
       s->active = active;
       if (!active) continue;
       any_active = 1; ++steps;
+      { const REAL pp[3] = { s->x, s->y, s->z }; FN(sig_cell)(i, h, pp); }
       REAL dn = FN(fdot3)(s->mx, s->my, s->mz, gx, gy, gz);
       REAL nds = (n * ds) * grad_scale;
       REAL val = dn * ds, ggx = nds * s->mx, ggy = nds * s->my, ggz = nds * s->mz;

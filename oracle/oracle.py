@@ -202,6 +202,24 @@ def backtrace(rif, res, xt, vt, dx, dv, h, ds, dtype=np.float32, sdf=None,
     return dict(grad=grad, steps_total=st.value)
 
 
+class trajectory_signatures:
+    """Context manager: while active, ``backtrace`` records for every ray a signature of the integer cells it
+    contributes in and its number of contributing steps (``.sig`` uint64[n], ``.steps`` int32[n]).  Rays whose
+    signatures agree between two arithmetics (fp32 factored vs fp64 literal) are free of cell-face tie events."""
+
+    def __init__(self, n: int):
+        self.sig = np.zeros(n, dtype=np.uint64)
+        self.steps = np.zeros(n, dtype=np.int32)
+
+    def __enter__(self):
+        lib().oracle_set_trajectory_sink(_p(self.sig), _p(self.steps))
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_trajectory_sink(None, None)
+        return False
+
+
 def backtrace_cable(rif, radius, length, xt, vt, dx, dv, ds, dtype=np.float32):
     """Tracer::backtrace_cable (src/tracer.cpp:511-567)."""
     s, R = _sfx(dtype), _real(dtype)

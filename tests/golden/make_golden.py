@@ -18,6 +18,11 @@ helpers -- plus the CPU oracle:
   fuel_injection.npz   data/fuel_injection_64.npy (float64, F-order) cast to fp32 and padded to 65^3
                        as core/fuel_injection_opt.py:40-43 does; forward exit rays from the oracle
 
+  splat_linear.npz     core/grid.py  Grid.SplatLinear (:275-315) RUN AS IS -> pins volume::splat (src/volume.cpp:182-244):
+                       value weights, signed gradient weights, index pattern, clamping
+  hessians.npz         torch.autograd (float64) through Grid.GetLinear / Cable.GetLinear RUN AS IS (Jacobian of their
+                       gradient output) -> pins volume::eval_hess (:40-99) and cylinder_volume::eval_hess (:61-111)
+
   sensor_splat.npz     core/sensor.py generate_sensor (:5-28) and torch.autograd through it, RUN AS IS in
                        float64 -> pins the sensor image splat and its backward
 
@@ -75,6 +80,56 @@ def getlinear_cable():
     pts[0, 0] = radius; pts[0, 2] = radius                            # r = 0 -> zero gradient branch
     f, fx = Cb.GetLinear(pts)
     save("getlinear_cable.npz", prof=prof.numpy(), radius=radius, pts=pts.numpy(), f=f.numpy(), fx=fx.numpy())
+
+
+def splat_linear():
+    """core/grid.py Grid.SplatLinear (:275-315) RUN AS IS: scene += wp*f + h*dot(fx, wi) at the 8 corners.  That is
+    volume::splat(p, val = f, grad = h*fx) (src/volume.cpp:182-244) on the axis-permuted scene for every point
+    SplatLinear keeps (0 <= p/h < res per axis) -- including the band res-1 <= p/h < res where the +1 neighbour is
+    clamped onto the same voxel.  Pins the 8 value weights, the sign pattern and index pattern of the 8 gradient
+    weights, and the clamping of the adjoint's scatter."""
+    torch.manual_seed(5)
+    R, h = 7, 0.5
+    n = 500
+    pts = torch.rand(n, 3, dtype=torch.float64) * R * h              # 0 <= p/h < R: includes the clamped band
+    pts[:40] = torch.rand(40, 3, dtype=torch.float64) * h + (R - 1) * h   # all three axes in the clamped band
+    pts[40] = torch.tensor([0.0, 0.0, 0.0], dtype=torch.float64)     # exactly on a corner
+    pts[41] = torch.tensor([1.0, 2.0, 1.5], dtype=torch.float64)     # exactly on voxel planes (w0 = 0)
+    f = torch.randn(n, dtype=torch.float64)
+    fx = torch.randn(n, 3, dtype=torch.float64)
+    G = ref_grid.Grid(torch.zeros(R, R, R, dtype=torch.float64), h)  # reference layout: scene[x,y,z]
+    G.weights = torch.zeros(R, R, R, dtype=torch.float64)
+    G.SplatLinear(pts, f, fx)
+    # stored in OUR layout scene[z,y,x]
+    save("splat_linear.npz", R=R, h=h, pts=pts.numpy(), f=f.numpy(), fx=fx.numpy(),
+         scene=G.scene.permute(2, 1, 0).contiguous().numpy(), weights=G.weights.permute(2, 1, 0).contiguous().numpy())
+
+
+def hessians_by_autograd():
+    """Second derivatives of the REFERENCE's own interpolants: torch.autograd (float64) through Grid.GetLinear
+    (:227-273) and Cable.GetLinear (:92-119) RUN AS IS -- the Jacobian of their gradient output with respect to
+    the sample position.  For the trilinear cell that is exactly what volume::eval_hess (src/volume.cpp:40-99)
+    writes out by hand: zero diagonal, the three mixed partials, / h^2 (Q10); for the radial profile it is
+    cylinder_volume::eval_hess (src/cylinder_volume.cpp:61-111): (I - rhat rhat^T)_{xz} n'/r with zero y row
+    and column.  Points strictly inside the grid / the profile and away from cell faces (where the interpolant's
+    gradient is discontinuous and autograd's one-sided value is a convention)."""
+    torch.manual_seed(7)
+    R, h = 8, 0.2
+    scene = torch.rand(R, R, R, dtype=torch.float64) + 1.0           # our layout scene[z,y,x]
+    G = ref_grid.Grid(scene.permute(2, 1, 0).contiguous(), h)
+    cells = torch.randint(0, R - 1, (200, 3)).to(torch.float64)
+    pts = (cells + 0.05 + 0.9 * torch.rand(200, 3, dtype=torch.float64)) * h
+    H = torch.stack([torch.autograd.functional.jacobian(lambda q: G.GetLinear(q[None, :])[1][0], p) for p in pts])
+    rres, radius = 13, 1.5
+    prof = torch.rand(rres, dtype=torch.float64) + 1.0
+    Cb = ref_cable.Cable(prof, radius, 10.0)
+    hc = radius / (rres - 1)
+    rr = (torch.randint(0, rres - 1, (150,)).to(torch.float64) + 0.05 + 0.9 * torch.rand(150, dtype=torch.float64)) * hc
+    ang = torch.rand(150, dtype=torch.float64) * 2 * np.pi
+    cp = torch.stack([radius + rr * torch.cos(ang), torch.rand(150, dtype=torch.float64) * 10, radius + rr * torch.sin(ang)], dim=-1)
+    Hc = torch.stack([torch.autograd.functional.jacobian(lambda q: Cb.GetLinear(q[None, :])[1][0], p) for p in cp])
+    save("hessians.npz", scene=scene.numpy(), h=h, pts=pts.numpy(), H=H.numpy(),
+         prof=prof.numpy(), radius=radius, cpts=cp.numpy(), Hc=Hc.numpy())
 
 
 def luneburg_cube():
@@ -229,6 +284,13 @@ def source_rays():
 
 
 if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    if only:                                   # e.g. `make_golden.py splat_linear hessians_by_autograd`
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
+    splat_linear()
+    hessians_by_autograd()
     getlinear_grid()
     getlinear_cable()
     luneburg_cube()
