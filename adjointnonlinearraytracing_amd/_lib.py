@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdrrt_hip.so")
+# DRRT_HIP_LIB: developer override (A-B builds of the same sources, e.g. other compiler flags); default = the in-tree build
+LIB_PATH = os.environ.get("DRRT_HIP_LIB") or os.path.join(_HERE, "libdrrt_hip.so")
 
 # flags (include/drrt_hip.h)
 FLAG_NONE = 0

@@ -110,7 +110,25 @@ DRRT_HD Cell locate(const Vol& V, float px, float py, float pz) {
   return c;
 }
 
-struct Taps { float v000, v100, v010, v110, v001, v101, v011, v111; };
+// The 8 taps of a cell, held as the four (x0, x0+1) PAIRS they are fetched as -- each pair is one register pair
+// that an 8-byte load fills directly, so a lane can keep its taps across steps (fetch_reuse) without copies:
+//   a = (v000, v100)  at (y0, z0)      b = (v010, v110)  at (y1, z0)
+//   e = (v001, v101)  at (y0, z1)      f = (v011, v111)  at (y1, z1)
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct Taps { f2 a, b, e, f; };
+
+DRRT_HD Taps taps_zero() { Taps t; t.a = t.b = t.e = t.f = f2{0.f, 0.f}; return t; }
+
+// One (x0, x0+1) pair: ONE 8-byte load on the device (global_load_dwordx2 needs only 4-byte alignment).
+DRRT_HD f2 ld_pair(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float __attribute__((ext_vector_type(2), aligned(4))) f2u;
+  const f2u a = *reinterpret_cast<const f2u*>(p);
+  return f2{a.x, a.y};
+#else
+  return f2{p[0], p[1]};
+#endif
+}
 
 DRRT_HD Taps fetch(const float* __restrict__ d, const Cell& c) {
   Taps t;
@@ -118,27 +136,16 @@ DRRT_HD Taps fetch(const float* __restrict__ d, const Cell& c) {
   __builtin_assume(c.base >= 0 && c.base < (1 << 29));   // make_vol() rejects grids of 2^29 voxels or more
 #endif
   const float* p = d + (unsigned)c.base;
-#if defined(__HIP_DEVICE_COMPILE__)
-  // The x-neighbour is the next float in memory: fetch each (x0, x0+1) pair with ONE 8-byte load
-  // (global_load_dwordx2 needs only 4-byte alignment).  The texture addresser handles a wave's
-  // gather at a few lanes per clock, so 4 pair loads instead of 8 dword loads halve the dominant
-  // cost of the march.  Cells clamped in x (ox == 0, only on the far x face) must not read p[1]:
+  // The x-neighbour is the next float in memory: fetch each (x0, x0+1) pair with ONE 8-byte load.  The texture
+  // addresser handles a wave's gather at a few lanes per clock, so 4 pair loads instead of 8 dword loads halve
+  // the dominant cost of the march.  Cells clamped in x (ox == 0, only on the far x face) must not read p[1]:
   // that could run past the end of the grid allocation.
   if (c.ox == 1) {
-    typedef float __attribute__((ext_vector_type(2), aligned(4))) f2u;
-    const f2u a = *reinterpret_cast<const f2u*>(p);
-    const f2u b = *reinterpret_cast<const f2u*>(p + c.oy);
-    const f2u e = *reinterpret_cast<const f2u*>(p + c.oz);
-    const f2u f = *reinterpret_cast<const f2u*>(p + c.oz + c.oy);
-    t.v000 = a.x; t.v100 = a.y; t.v010 = b.x; t.v110 = b.y;
-    t.v001 = e.x; t.v101 = e.y; t.v011 = f.x; t.v111 = f.y;
+    t.a = ld_pair(p); t.b = ld_pair(p + c.oy); t.e = ld_pair(p + c.oz); t.f = ld_pair(p + c.oz + c.oy);
     return t;
   }
-#endif
-  t.v000 = p[0];            t.v100 = p[c.ox];
-  t.v010 = p[c.oy];         t.v110 = p[c.oy + c.ox];
-  t.v001 = p[c.oz];         t.v101 = p[c.oz + c.ox];
-  t.v011 = p[c.oz + c.oy];  t.v111 = p[c.oz + c.oy + c.ox];
+  t.a = f2{p[0], p[c.ox]};                t.b = f2{p[c.oy], p[c.oy + c.ox]};
+  t.e = f2{p[c.oz], p[c.oz + c.ox]};      t.f = f2{p[c.oz + c.oy], p[c.oz + c.oy + c.ox]};
   return t;
 }
 
@@ -153,12 +160,45 @@ DRRT_HD Taps fetch_vol(const Vol& V, const Cell& c) {
     const float4 a = V.quad[(unsigned)c.base];
     const float4 b = V.quad[(unsigned)c.base + (unsigned)V.sz];
     Taps t;
-    t.v000 = a.x; t.v100 = a.y; t.v010 = a.z; t.v110 = a.w;
-    t.v001 = b.x; t.v101 = b.y; t.v011 = b.z; t.v111 = b.w;
+    t.a = f2{a.x, a.y}; t.b = f2{a.z, a.w};
+    t.e = f2{b.x, b.y}; t.f = f2{b.z, b.w};
     return t;
   }
 #endif
   return fetch(V.data, c);
+}
+
+// ---- tap reuse ------------------------------------------------------------------------------------
+// With ds = h/step_res a ray samples the same cell ~step_res times in a row, and the cell it moves on to
+// shares a face -- 4 of the 8 taps -- with the one it leaves.  The march's limiter is the texture addresser,
+// whose cost is per lane-address (above), so the taps a lane already holds are kept in registers:
+//   REUSE 1  same cell as the previous step: no load at all;
+//   REUSE 2  additionally, a move across ONE y- or z-face keeps the two (x0, x0+1) pairs of the shared face and
+//            loads only the two pairs of the new far face (an x-move would still need four pair loads: the
+//            pairs straddle it).
+// Only strictly interior cells are cached (regular strides, 8 distinct taps).  The floats are the ones a full
+// fetch would return, so results are bit-identical (tests: hostcheck on the CPU, GPU parity vs the oracle).
+struct TapCache { Taps t; int base; };     // base < 0: nothing cached
+
+template <int REUSE>
+DRRT_HD void fetch_reuse(const Vol& V, const Cell& c, TapCache& tc) {
+  if (REUSE == 0 || V.quad != nullptr) { tc.t = fetch_vol(V, c); return; }
+  if (!c.interior) { tc.t = fetch(V.data, c); tc.base = -1; return; }
+  if (c.base == tc.base) return;
+  Taps& t = tc.t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_assume(c.base >= 0 && c.base < (1 << 29));
+#endif
+  const float* p = V.data + (unsigned)c.base;
+  if (REUSE >= 2 && tc.base >= 0) {
+    const int d = c.base - tc.base;
+    if (d == V.sy)  { t.a = t.b; t.e = t.f; t.b = ld_pair(p + V.sy); t.f = ld_pair(p + V.sz + V.sy); tc.base = c.base; return; }   // +y
+    if (d == -V.sy) { t.b = t.a; t.f = t.e; t.a = ld_pair(p);        t.e = ld_pair(p + V.sz);        tc.base = c.base; return; }   // -y
+    if (d == V.sz)  { t.a = t.e; t.b = t.f; t.e = ld_pair(p + V.sz); t.f = ld_pair(p + V.sz + V.sy); tc.base = c.base; return; }   // +z
+    if (d == -V.sz) { t.e = t.a; t.f = t.b; t.a = ld_pair(p);        t.b = ld_pair(p + V.sy);        tc.base = c.base; return; }   // -z
+  }
+  t.a = ld_pair(p); t.b = ld_pair(p + V.sy); t.e = ld_pair(p + V.sz); t.f = ld_pair(p + V.sz + V.sy);
+  tc.base = c.base;
 }
 
 // n and RAW gradient / mixed partials (not yet multiplied by 1/h, 1/h^2).
@@ -168,10 +208,10 @@ template <bool WITH_HESS>
 DRRT_HD Sample interp(const Taps& t, float wx, float wy, float wz) {
   Sample s;
   // x-differences at the four (y,z) edges
-  float d00 = t.v100 - t.v000, d10 = t.v110 - t.v010, d01 = t.v101 - t.v001, d11 = t.v111 - t.v011;
+  float d00 = t.a.y - t.a.x, d10 = t.b.y - t.b.x, d01 = t.e.y - t.e.x, d11 = t.f.y - t.f.x;
   // x-lerped values
-  float c00 = fmaf(wx, d00, t.v000), c10 = fmaf(wx, d10, t.v010);
-  float c01 = fmaf(wx, d01, t.v001), c11 = fmaf(wx, d11, t.v011);
+  float c00 = fmaf(wx, d00, t.a.x), c10 = fmaf(wx, d10, t.b.x);
+  float c01 = fmaf(wx, d01, t.e.x), c11 = fmaf(wx, d11, t.f.x);
   float e0 = c10 - c00, e1 = c11 - c01;                  // d/dy at z0, z1
   float l0 = fmaf(wy, e0, c00), l1 = fmaf(wy, e1, c01);  // (x,y)-lerped at z0, z1
   float dz = l1 - l0;
@@ -305,10 +345,17 @@ DRRT_HD bool plane_again(const Vol& V, const FwdState& s) {
 
 template <int MODE>
 DRRT_HD void fwd_step(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s, Cell& c) {
-  Taps t;
-  t.v000 = t.v100 = t.v010 = t.v110 = t.v001 = t.v101 = t.v011 = t.v111 = 0.f;
+  Taps t = taps_zero();
   if (s.inside) t = fetch_vol(V, c);
   fwd_step_c<MODE>(V, sdf, ds, s, c, t);
+}
+
+// The same with the taps the lane already holds kept across steps (fetch_reuse).  A ray that is not inside does
+// not sample (Q4) and fwd_step_c ignores the taps then, so the cache is simply left alone.
+template <int MODE, int REUSE>
+DRRT_HD void fwd_step_r(const Vol& V, const float* __restrict__ sdf, float ds, FwdState& s, Cell& c, TapCache& tc) {
+  if (s.inside) fetch_reuse<REUSE>(V, c, tc);
+  fwd_step_c<MODE>(V, sdf, ds, s, c, tc.t);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -463,7 +510,9 @@ DRRT_HD bool cable_adj_step(const Cyl& C, float ds, AdjState& s, int& i0, int& i
 struct RayOut { float xt[3], vt[3]; float dist2; bool esc, act, again; unsigned steps; };
 
 // trace / trace_plane / trace_sdf for ONE ray, per-ray termination (see drrt_kernels.hip header)
-template <int MODE>
+constexpr int kTapReuse = 2;      // product default of the forward marches (see fetch_reuse)
+
+template <int MODE, int REUSE = kTapReuse>
 DRRT_HD RayOut trace_ray(const Vol& V, const float* __restrict__ sdf, float ds, int max_steps,
                          const float p[3], const float v[3], const float* pln_o, const float* pln_d) {
   FwdState s;
@@ -478,8 +527,11 @@ DRRT_HD RayOut trace_ray(const Vol& V, const float* __restrict__ sdf, float ds, 
   bool act = true;
   if (MODE == 2) act = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n < 0.f;   // src/tracer.cpp:276-277
   unsigned steps = 0;
+  TapCache tc;
+  tc.base = -1;
+  tc.t = taps_zero();
   for (int it = 0; it < max_steps; ++it) {
-    fwd_step<MODE>(V, sdf, ds, s, c);
+    fwd_step_r<MODE, REUSE>(V, sdf, ds, s, c, tc);
     ++steps;
     if (s.esc) break;                                                     // per-ray form of :82
   }
@@ -523,6 +575,7 @@ DRRT_HD RayOut ray_full(const Vol& V, const float* __restrict__ sdf, float ds, u
 
 // trace_target phase A for ONE ray: march until escaped, track the closest approach;
 // `cont` receives the marching state (x, v) for phase B.
+template <int REUSE = kTapReuse>
 DRRT_HD RayOut target_ray_a(const Vol& V, float ds, int max_steps, const float p[3], const float v[3],
                             const float tg[3], float cont[6]) {
   FwdState s;
@@ -533,8 +586,11 @@ DRRT_HD RayOut target_ray_a(const Vol& V, float ds, int max_steps, const float p
   fwd_init(V, s);
   Cell c = locate(V, s.x, s.y, s.z);
   unsigned steps = 0;
+  TapCache tc;
+  tc.base = -1;
+  tc.t = taps_zero();
   for (int it = 0; it < max_steps; ++it) {
-    fwd_step<3>(V, nullptr, ds, s, c);
+    fwd_step_r<3, REUSE>(V, nullptr, ds, s, c, tc);
     ++steps;
     if (s.esc) break;
   }

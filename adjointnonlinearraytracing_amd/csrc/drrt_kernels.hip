@@ -100,7 +100,7 @@ struct TraceArgs {
   int max_steps;
 };
 
-template <int MODE>
+template <int MODE, int REUSE = kTapReuse>
 __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
   unsigned steps = 0, failed = 0;
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
       Ray3 o = ld3(a.pln_o, i), d = ld3(a.pln_d, i);
       po[0] = o.x; po[1] = o.y; po[2] = o.z; pd[0] = d.x; pd[1] = d.y; pd[2] = d.z;
     }
-    RayOut r = trace_ray<MODE>(a.vol, a.sdf, a.ds, a.max_steps, pp, vv, po, pd);
+    RayOut r = trace_ray<MODE, REUSE>(a.vol, a.sdf, a.ds, a.max_steps, pp, vv, po, pd);
     steps = r.steps; failed = r.act ? 1u : 0u;
     st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2], a.io_half);
     st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2], a.io_half);
@@ -215,10 +215,8 @@ __device__ __forceinline__ bool nwin_local(int wox, int woy, int woz, const Cell
 __device__ __forceinline__ Taps fetch_lds(const float* nw, int lidx) {
   const float* q = nw + lidx;
   Taps t;
-  t.v000 = q[0];              t.v100 = q[1];
-  t.v010 = q[kBSY];           t.v110 = q[kBSY + 1];
-  t.v001 = q[kBSZ];           t.v101 = q[kBSZ + 1];
-  t.v011 = q[kBSZ + kBSY];    t.v111 = q[kBSZ + kBSY + 1];
+  t.a = f2{q[0], q[1]};                       t.b = f2{q[kBSY], q[kBSY + 1]};
+  t.e = f2{q[kBSZ], q[kBSZ + 1]};             t.f = f2{q[kBSZ + kBSY], q[kBSZ + kBSY + 1]};
   return t;
 }
 
@@ -279,8 +277,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
       --cooldown;
     }
     if (live) {
-      Taps tp;
-      tp.v000 = tp.v100 = tp.v010 = tp.v110 = tp.v001 = tp.v101 = tp.v011 = tp.v111 = 0.f;
+      Taps tp = taps_zero();
       if (inw) tp = fetch_lds(nw, lidx);
       else if (need) tp = fetch(V.data, c);
       fwd_step_c<MODE>(V, nullptr, a.ds, s, c, tp);
@@ -1072,8 +1069,15 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
   a.max_steps = (MODE == 2) ? steps_sdf(h, res, ds) : steps_fwd(h, res, ds);
   {
     ProfScope prof(DRRT_PROF_TRACE, s);
-    if (MODE == 2 || !(flags & DRRT_FLAG_LDS_BRICKS))
-      hipLaunchKernelGGL(k_trace<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    if (MODE == 2 || !(flags & DRRT_FLAG_LDS_BRICKS)) {
+      const unsigned reuse = (flags & DRRT_FLAG_TAP_REUSE_MASK);
+      if (reuse == DRRT_FLAG_TAP_REUSE_OFF)
+        hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      else if (reuse == DRRT_FLAG_TAP_REUSE_CELL)
+        hipLaunchKernelGGL((k_trace<MODE, 1>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      else
+        hipLaunchKernelGGL((k_trace<MODE, 2>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    }
     else
       hipLaunchKernelGGL(k_trace_win<(MODE == 2 ? 0 : MODE)>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
   }

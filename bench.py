@@ -80,6 +80,9 @@ def parse_args(argv=None):
     ap.add_argument("--experiment", type=int, default=0, help="development ablation id (0 = product)")
     ap.add_argument("--fwd-flags", type=lambda v: int(v, 0), default=0, help="extra DRRT_FLAG_* bits for the forward call")
     ap.add_argument("--adj-flags", type=lambda v: int(v, 0), default=0, help="extra DRRT_FLAG_* bits for the adjoint call")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="G",
+                    help="single process: march only shard 0 of G of the strong-scaling ray set (what ONE rank of a G-GPU "
+                         "run does, without the all-reduce) -- per-shard timings for the scaling projection in DESIGN.md")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
                                                         "to rehearse the multi-rank flow on a 1-GPU box)")
@@ -338,6 +341,8 @@ def run_rank(args) -> int:
         if mode == "strong":
             gpos, gvel = make_rays(args.rays, seed=0)              # the metric's single ray set, same on every rank
             lo, hi = drrt_dist.shard_bounds(args.rays, rank, world)
+            if args.shard_of > 1 and world == 1:
+                lo, hi = drrt_dist.shard_bounds(args.rays, 0, args.shard_of)
             pos, vel = gpos[lo:hi].contiguous().to(dev), gvel[lo:hi].contiguous().to(dev)
         else:
             pos, vel = (t.to(dev) for t in make_rays(args.rays, seed=rank))
@@ -449,7 +454,8 @@ def run_rank(args) -> int:
                        "rays_rank0": n, "fwd_ray_steps_rank0": fwd_steps, "adj_ray_steps_rank0": adj_steps,
                        "fwd_ray_steps_global": m["fwd_total"], "n_failed": m["n_failed"],
                        "sort_rays": not args.no_sort, "quad_grid": bool(flags & _lib.FLAG_QUAD_GRID),
-                       "parallelism": f"ray-shard x{world}", "backend": args.backend if use_dist else None},
+                       "parallelism": f"ray-shard x{world}", "backend": args.backend if use_dist else None,
+                       "shard_of": args.shard_of or None},
             "roofline": roof,
             "roofline_fwd": roof_f,
             "phase_ms": {"sort_avg": m["ms_sort"], "zero_grid": m["ms_zero"],

@@ -73,6 +73,10 @@ extern "C" {
 #define DRRT_FLAG_QUAD_REUSE  128u  /* with QUAD_GRID: the workspace still holds the quad copy built by the previous
                                        call (same rif contents, same n, same flags & SORT_RAYS, same workspace) --
                                        e.g. the adjoint paired with its forward: skip the rebuild                  */
+#define DRRT_FLAG_TAP_REUSE_MASK 0x30000u /* trace / trace_pln / trace_sdf (A-B measurement; results are bit-identical):   */
+#define DRRT_FLAG_TAP_REUSE_OFF  0x10000u /*   gather all 8 taps at every step                                              */
+#define DRRT_FLAG_TAP_REUSE_CELL 0x20000u /*   skip the gather only while the ray stays in the same cell                    */
+                                        /*   default (0): also keep the shared face across a y- or z-move (2 pair loads)  */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
                                        written to the last 512 bytes of the workspace:
                                        [0] LDS-window flushes, [1] ray-steps accumulated through
