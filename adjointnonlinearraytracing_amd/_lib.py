@@ -58,6 +58,8 @@ SIGNATURES = {
     "drrt_backtrace_cable_f32": (_i, [_vp, _sz, _f, _f, _sz, _vp, _vp, _vp, _vp, _f, _vp] + _tail),
     "drrt_sensor_splat_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _u, _vp]),
     "drrt_sensor_splat_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "drrt_sensor_far_splat_f32": (_i, [_sz, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _u, _vp]),
+    "drrt_sensor_far_splat_bwd_f32": (_i, [_sz, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "drrt_upres_volume_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "drrt_gen_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "drrt_gen_rays_f32": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <hip/hip_fp16.h>
 
@@ -1026,6 +1027,38 @@ static int maybe_sort(const Vol& V, float h, size_t n, const void* pos, const vo
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
+// ---- spreading small grids over the whole chip -------------------------------------------------------------
+// A march kernel admits several 256-thread blocks per CU (forward: 8 by registers; adjoint: 4 by its 34 KiB of LDS
+// windows), and the dispatcher fills a CU to that limit before it moves on: a grid of 512 blocks -- one rank's shard
+// of the 1M-ray workload at 8 GPUs -- then occupies a quarter to a half of the 256 CUs and runs 2-3x longer than
+// its share of the work (measured: 131072 rays, forward 0.59 ms / adjoint 1.51 ms against 0.19 / 0.69 ms for an
+// eighth of the full launch).  The only occupancy knob a launch has is its LDS size, so grids that cannot fill the
+// chip anyway ask for enough (unused) dynamic LDS that at most ceil(blocks / CUs) blocks fit one CU.
+static int device_cus() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cus[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev] = v;
+  }
+  return cus[dev];
+}
+
+static size_t spread_lds_bytes(unsigned blocks, size_t static_lds, unsigned natural_blocks_per_cu) {
+  static const int off = [] { const char* e = getenv("DRRT_DEV_NO_SPREAD"); return (e && e[0] == '1') ? 1 : 0; }();
+  if (off || blocks == 0) return 0;
+  const unsigned cus = (unsigned)device_cus();
+  const unsigned want = (blocks + cus - 1) / cus;                  // blocks per CU if spread evenly
+  if (want >= natural_blocks_per_cu) return 0;                       // the grid fills the chip as it is
+  const size_t kLds = 160 * 1024;
+  size_t per_block = (kLds / want) & ~(size_t)511;                   // floor(160 KiB / per_block) == want blocks fit one CU
+  if (per_block > 64 * 1024) per_block = 64 * 1024;                  // a block's LDS above 64 KiB needs an opt-in attribute;
+                                                                     // 64 KiB already caps a CU at 2 blocks
+  return per_block > static_lds ? per_block - static_lds : 0;
+}
+
 template <int MODE>
 static int run_trace(const float* rif, const float* sdf, long long nvox, const int res[3], size_t n,
                      const void* pos, const void* vel, const float* pln_o, const float* pln_d,
@@ -1071,12 +1104,13 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
     ProfScope prof(DRRT_PROF_TRACE, s);
     if (MODE == 2 || !(flags & DRRT_FLAG_LDS_BRICKS)) {
       const unsigned reuse = (flags & DRRT_FLAG_TAP_REUSE_MASK);
+      const size_t pad = spread_lds_bytes(grid_for(n), 64, 8);
       if (reuse == DRRT_FLAG_TAP_REUSE_OFF)
-        hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
-      else if (reuse == DRRT_FLAG_TAP_REUSE_CELL)
-        hipLaunchKernelGGL((k_trace<MODE, 1>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(grid_for(n)), dim3(kBlock), pad, s, a);
+      else if (reuse == DRRT_FLAG_TAP_REUSE_FACE)
+        hipLaunchKernelGGL((k_trace<MODE, 2>), dim3(grid_for(n)), dim3(kBlock), pad, s, a);
       else
-        hipLaunchKernelGGL((k_trace<MODE, 2>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((k_trace<MODE, 1>), dim3(grid_for(n)), dim3(kBlock), pad, s, a);
     }
     else
       hipLaunchKernelGGL(k_trace_win<(MODE == 2 ? 0 : MODE)>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
@@ -1196,7 +1230,8 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
     else if (a.experiment != 0 || a.dbg != nullptr)
       hipLaunchKernelGGL((k_backtrace_win<MODE, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
     else
-      hipLaunchKernelGGL((k_backtrace_win<MODE, false>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_backtrace_win<MODE, false>), dim3(grid_for(n)), dim3(kBlock),
+                         spread_lds_bytes(grid_for(n), sizeof(win_t) * kWavesPerBlock * kWinFloats + 64, 4), s, a);
   }
   LAUNCH_CHECK("k_backtrace");
   return DRRT_OK;

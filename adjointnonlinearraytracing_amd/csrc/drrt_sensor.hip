@@ -5,6 +5,9 @@
 //   sensor.py:195-202  trace_rays_to_plane   t = n.(p - x) / n.v ;  x' = x + t v
 //   sensor.py:5-28     generate_sensor       2-D coords of x' in the sensor frame (t1 = n x t2, t2),
 //                                            foreshortening fs = |v.n|, Grid.Splat(xn, fs*e, average=False)
+//   sensor.py:31-53    generate_inf_sensor   far-field ("infinite distance") sensor: 2-D coords of the NORMALISED
+//                                            direction in the sensor frame + ang_cut, ang_cut = sin(angle_span/2),
+//                                            cell size 2*ang_cut/res, weight e (no foreshortening), same Splat
 //   grid.py:37-64      Grid.index_values     u = xn/h - 0.5, 4x4 taps around floor(u), r = |u - idx|
 //   grid.py:77-81      rbf_tent              w = max(sqrt(2) - r, 0)
 //   grid.py:133-151    Grid.Splat            image[idx] += w/sum(w) * f  for taps inside the image
@@ -26,6 +29,7 @@ struct SensorArgs {
   float e_scalar;
   float p[3], n[3], t1[3], t2[3];
   int res; float span, inv_hs, half_span;
+  int far;                     // 1: generate_inf_sensor (coordinates from the direction only; span = 2*ang_cut)
   float* image;                // forward out (res*res)
   const float* grad_image;     // backward in
   float* grad_x; float* grad_v;
@@ -42,6 +46,20 @@ __device__ __forceinline__ SensorRay sensor_locate(const SensorArgs& a, size_t i
   SensorRay r;
   x[0] = a.x[3 * i]; x[1] = a.x[3 * i + 1]; x[2] = a.x[3 * i + 2];
   v[0] = a.v[3 * i]; v[1] = a.v[3 * i + 1]; v[2] = a.v[3 * i + 2];
+  if (a.far) {                                                          // sensor.py:36-47
+    const float nv = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float inv = 1.f / nv;
+    const float h0 = v[0] * inv, h1 = v[1] * inv, h2 = v[2] * inv;      // v / norm(v)
+    const float xa = h0 * a.t1[0] + h1 * a.t1[1] + h2 * a.t1[2] + a.half_span;   // + ang_cut
+    const float xb = h0 * a.t2[0] + h1 * a.t2[1] + h2 * a.t2[2] + a.half_span;
+    r.den = nv; r.t = 0.f;
+    r.u[0] = xa * a.inv_hs - 0.5f; r.u[1] = xb * a.inv_hs - 0.5f;
+    const float f0 = floorf(r.u[0]), f1 = floorf(r.u[1]);
+    r.ok = (f0 >= -3.f) & (f0 <= (float)(a.res + 1)) & (f1 >= -3.f) & (f1 <= (float)(a.res + 1));
+    r.i1[0] = r.ok ? (int)f0 : 0; r.i1[1] = r.ok ? (int)f1 : 0;
+    r.F = a.e ? a.e[i] : a.e_scalar;                                    // :49 (no foreshortening)
+    return r;
+  }
   r.den = v[0] * a.n[0] + v[1] * a.n[1] + v[2] * a.n[2];
   const float num = (a.p[0] - x[0]) * a.n[0] + (a.p[1] - x[1]) * a.n[1] + (a.p[2] - x[2]) * a.n[2];
   r.t = num / r.den;                                                  // sensor.py:199-200
@@ -176,6 +194,16 @@ __global__ void __launch_bounds__(256) k_sensor_splat_bwd(SensorArgs a) {
     const float k = r.F / W * a.inv_hs;
     const float ga = k * (gda - G * sda), gb = k * (gdb - G * sdb);    // dL/d xn
     const float gp0 = ga * a.t1[0] + gb * a.t2[0], gp1 = ga * a.t1[1] + gb * a.t2[1], gp2 = ga * a.t1[2] + gb * a.t2[2];
+    if (a.far) {
+      // coordinates depend on v only, through vhat = v/|v|:  d vhat / d v = (I - vhat vhat^T) / |v|
+      const float inv = 1.f / r.den;
+      const float h0 = v[0] * inv, h1 = v[1] * inv, h2 = v[2] * inv;
+      const float hg = h0 * gp0 + h1 * gp1 + h2 * gp2;
+      gv[0] = (gp0 - h0 * hg) * inv; gv[1] = (gp1 - h1 * hg) * inv; gv[2] = (gp2 - h2 * hg) * inv;
+      a.grad_x[3 * i] = 0.f; a.grad_x[3 * i + 1] = 0.f; a.grad_x[3 * i + 2] = 0.f;
+      a.grad_v[3 * i] = gv[0]; a.grad_v[3 * i + 1] = gv[1]; a.grad_v[3 * i + 2] = gv[2];
+      return;
+    }
     const float vg = (v[0] * gp0 + v[1] * gp1 + v[2] * gp2) / r.den;
     gx[0] = gp0 - a.n[0] * vg; gx[1] = gp1 - a.n[1] * vg; gx[2] = gp2 - a.n[2] * vg;     // (I - v n^T/den)^T
     const float ef = G * (a.e ? a.e[i] : a.e_scalar) * (r.den > 0.f ? 1.f : (r.den < 0.f ? -1.f : 0.f));
@@ -194,6 +222,7 @@ static int fill_args(SensorArgs& a, size_t n, const float* x, const float* v, co
   a.x = x; a.v = v; a.e = e; a.e_scalar = e_scalar; a.n_rays = n;
   for (int k = 0; k < 3; ++k) { a.p[k] = p[k]; a.n[k] = nrm[k]; a.t1[k] = t1[k]; a.t2[k] = t2[k]; }
   a.res = res; a.span = span; a.inv_hs = 1.0f / (span / (float)res); a.half_span = span / 2;
+  a.far = 0;
   return DRRT_OK;
 }
 
@@ -226,6 +255,49 @@ extern "C" int drrt_sensor_splat_bwd_f32(size_t n, const float* x, const float* 
                                          float* grad_x, float* grad_v, void* stream) {
   SensorArgs a{};
   int rc = fill_args(a, n, x, v, e, e_scalar, plane_p, plane_n, t1, t2, res, span); if (rc) return rc;
+  if (!grad_image || !grad_x || !grad_v) return sensor_fail(DRRT_ERR_ARG, "null gradient pointer");
+  if (n == 0) return DRRT_OK;
+  a.grad_image = grad_image; a.grad_x = grad_x; a.grad_v = grad_v;
+  hipLaunchKernelGGL(k_sensor_splat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+
+// ---- far-field sensor (core/sensor.py:31-53 generate_inf_sensor, called at core/image_opt.py:116) ----------------
+// Same splat kernels with SensorArgs::far set: `ang_cut` = sin(0.5 * deg2rad(angle_span)) is computed by the caller
+// (the reference evaluates it in the rays' dtype, sensor.py:38); the image spans [0, 2*ang_cut)^2.
+static int fill_far(SensorArgs& a, size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
+                    const float t2[3], int res, float ang_cut) {
+  const float zero[3] = {0.f, 0.f, 0.f};
+  int rc = fill_args(a, n, v, v, e, e_scalar, zero, zero, t1, t2, res, 2.0f * ang_cut); if (rc) return rc;
+  a.half_span = ang_cut; a.inv_hs = 1.0f / (2.0f * ang_cut / (float)res);   // Grid(zeros, 2*ang_cut/res), :44
+  a.far = 1;
+  return DRRT_OK;
+}
+
+extern "C" int drrt_sensor_far_splat_f32(size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
+                                         const float t2[3], int res, float ang_cut, float* image, unsigned flags,
+                                         void* stream) {
+  SensorArgs a{};
+  int rc = fill_far(a, n, v, e, e_scalar, t1, t2, res, ang_cut); if (rc) return rc;
+  if (!image) return sensor_fail(DRRT_ERR_ARG, "null image pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (!(flags & DRRT_FLAG_NO_ZERO)) {
+    hipError_t e_ = hipMemsetAsync(image, 0, (size_t)res * res * sizeof(float), s);
+    if (e_ != hipSuccess) return sensor_fail(DRRT_ERR_HIP, hipGetErrorString(e_));
+  }
+  if (n == 0) return DRRT_OK;
+  a.image = image;
+  hipLaunchKernelGGL(k_sensor_splat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+
+extern "C" int drrt_sensor_far_splat_bwd_f32(size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
+                                             const float t2[3], int res, float ang_cut, const float* grad_image,
+                                             float* grad_x, float* grad_v, void* stream) {
+  SensorArgs a{};
+  int rc = fill_far(a, n, v, e, e_scalar, t1, t2, res, ang_cut); if (rc) return rc;
   if (!grad_image || !grad_x || !grad_v) return sensor_fail(DRRT_ERR_ARG, "null gradient pointer");
   if (n == 0) return DRRT_OK;
   a.grad_image = grad_image; a.grad_x = grad_x; a.grad_v = grad_v;

@@ -20,7 +20,7 @@
 // The permutation only changes the VISIT order; results are written back in the caller's ray order.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <stdint.h>
 
 #include "drrt_device.h"
@@ -80,11 +80,11 @@ __global__ void __launch_bounds__(256) k_chord_keys(Vol V, size_t n, const void*
 
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
-static size_t cub_temp_bytes(size_t n) {
+static size_t radix_temp_bytes(size_t n) {
   size_t temp = 0;
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, kKeyBits,
-                                                   (hipStream_t)0);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, temp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                          (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0u, (unsigned)kKeyBits,
+                                          (hipStream_t)0);
   if (e != hipSuccess || temp == 0) {   // no device visible (CPU-only import): conservative bound
     (void)hipGetLastError();
     temp = n * 32 + (1u << 20);
@@ -93,7 +93,7 @@ static size_t cub_temp_bytes(size_t n) {
 }
 
 size_t sort_workspace_bytes(size_t n) {
-  return 2 * al(n * sizeof(uint64_t)) + 2 * al(n * sizeof(uint32_t)) + al(cub_temp_bytes(n));
+  return 2 * al(n * sizeof(uint64_t)) + 2 * al(n * sizeof(uint32_t)) + al(radix_temp_bytes(n));
 }
 
 hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void* pos, const void* vel, int io_half,
@@ -112,8 +112,8 @@ hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void*
                      io_half, dir_sign, keys_in, idx_in);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint64_t*)keys_in, keys_out,
-                                         (const uint32_t*)idx_in, idx_out, (int)n, 0, kKeyBits, stream);
+  e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint64_t*)keys_in, keys_out,
+                                (const uint32_t*)idx_in, idx_out, n, 0u, (unsigned)kKeyBits, stream);
   *perm_out = idx_out;
   return e;
 }

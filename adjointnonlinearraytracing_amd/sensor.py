@@ -1,7 +1,8 @@
 """Counterpart of the part of the reference's ``core/sensor.py`` that directly follows the march:
-``trace_rays_to_plane`` (``:195-202``), ``get_tan_vecs`` (``:219-231``) and ``generate_sensor``
+``trace_rays_to_plane`` (``:195-202``), ``get_tan_vecs`` (``:219-231``), ``generate_sensor``
 (``:5-28``), the differentiable 2-D image splat used by the image / Luneburg experiments
-(``core/image_opt.py:99-101``, ``core/luneburg_opt.py:121-123``).
+(``core/image_opt.py:99-101``, ``core/luneburg_opt.py:121-123``), and ``generate_inf_sensor`` (``:31-53``),
+the far-field (direction histogram) sensor of the image experiments (``core/image_opt.py:116``).
 
 ``generate_sensor`` keeps the reference's signature; on ``cuda`` (ROCm) tensors it runs the fused
 HIP kernels (``csrc/drrt_sensor.hip``: ray -> plane -> sensor frame -> 16 tent taps -> atomics, and
@@ -95,3 +96,54 @@ def generate_sensor(rays, e, plane, res, span, tangent=None):
     p, n = plane
     t1, t2 = get_tan_vecs(n, tangent)
     return _SensorSplat.apply(x, v, e, p, n, t1, t2, res, span)
+
+
+class _FarSensorSplat(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, v, e, t1, t2, res, ang_cut):
+        if not v.is_cuda:
+            raise RuntimeError("generate_inf_sensor expects tensors on the cuda (ROCm) device (no CPU path)")
+        dev = v.device
+        with torch.cuda.device(dev):
+            v_ = v.detach().to(torch.float32).contiguous()
+            nr = v_.shape[0]
+            if isinstance(e, torch.Tensor) and e.numel() > 1:
+                e_ = e.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+                if e_.numel() != nr:
+                    raise RuntimeError("e must be a scalar or have one entry per ray")
+                e_s = 0.0
+            else:
+                e_, e_s = None, float(e)
+            img = torch.empty(int(res), int(res), dtype=torch.float32, device=dev)
+            frame = (_vec3(t1), _vec3(t2))
+            _lib.check(_lib.load().drrt_sensor_far_splat_f32(
+                nr, C.c_void_p(v_.data_ptr()), C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s, *frame,
+                int(res), float(ang_cut), C.c_void_p(img.data_ptr()), 0,
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.saved = (v_, e_, e_s, frame, int(res), float(ang_cut))
+        return img
+
+    @staticmethod
+    def backward(ctx, grad_img):
+        v_, e_, e_s, frame, res, ang_cut = ctx.saved
+        dev = v_.device
+        with torch.cuda.device(dev):
+            g = grad_img.detach().to(torch.float32).contiguous()
+            gx, gv = torch.empty_like(v_), torch.empty_like(v_)
+            _lib.check(_lib.load().drrt_sensor_far_splat_bwd_f32(
+                v_.shape[0], C.c_void_p(v_.data_ptr()), C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s, *frame,
+                res, ang_cut, C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()), C.c_void_p(gv.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return gv, None, None, None, None, None
+
+
+def generate_inf_sensor(rays, e, plane, res, angle_span=120, tangent=None):
+    """core/sensor.py:31-53: far-field image (res, res) -- the normalised ray directions splatted in the sensor
+    frame over [-ang_cut, ang_cut]^2, ang_cut = sin(angle_span / 2); differentiable w.r.t. the directions (the
+    positions do not enter, as in the reference)."""
+    x, v = rays
+    p, n = plane
+    ang_cut = float(torch.sin(0.5 * torch.deg2rad(torch.tensor(float(angle_span), dtype=torch.float32))))   # :38
+    t1, t2 = get_tan_vecs(n, tangent)
+    return _FarSensorSplat.apply(v, e, t1, t2, res, ang_cut)

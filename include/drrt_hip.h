@@ -75,8 +75,8 @@ extern "C" {
                                        e.g. the adjoint paired with its forward: skip the rebuild                  */
 #define DRRT_FLAG_TAP_REUSE_MASK 0x30000u /* trace / trace_pln / trace_sdf (A-B measurement; results are bit-identical):   */
 #define DRRT_FLAG_TAP_REUSE_OFF  0x10000u /*   gather all 8 taps at every step                                              */
-#define DRRT_FLAG_TAP_REUSE_CELL 0x20000u /*   skip the gather only while the ray stays in the same cell                    */
-                                        /*   default (0): also keep the shared face across a y- or z-move (2 pair loads)  */
+#define DRRT_FLAG_TAP_REUSE_FACE 0x20000u /*   also keep the shared face across a y- or z-move (2 pair loads instead of 4)  */
+                                          /*   default (0): skip the gather while the ray stays in the same cell            */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
                                        written to the last 512 bytes of the workspace:
                                        [0] LDS-window flushes, [1] ray-steps accumulated through
@@ -239,6 +239,16 @@ DRRT_API int drrt_sensor_splat_bwd_f32(size_t n, const float* x, const float* v,
                               const float plane_p[3], const float plane_n[3], const float t1[3], const float t2[3],
                               int res, float span, const float* grad_image, float* grad_x, float* grad_v,
                               void* stream);
+
+/* Far-field sensor: core/sensor.py:31-53 generate_inf_sensor (called at core/image_opt.py:116).  The image is a
+ * histogram of the NORMALISED ray directions in the sensor frame: coordinates (vhat.t1, vhat.t2) + ang_cut with
+ * ang_cut = sin(0.5 * deg2rad(angle_span)) computed by the caller (sensor.py:38), cell size 2*ang_cut/res, weight e
+ * (no foreshortening), the same Grid.Splat.  Positions do not enter; the backward writes grad_x = 0.            */
+DRRT_API int drrt_sensor_far_splat_f32(size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
+                              const float t2[3], int res, float ang_cut, float* image, unsigned flags, void* stream);
+DRRT_API int drrt_sensor_far_splat_bwd_f32(size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
+                                  const float t2[3], int res, float ang_cut, const float* grad_image,
+                                  float* grad_x, float* grad_v, void* stream);
 
 /* ---- multires up-sampling (SURVEY.md 8.8 "next" row 3) --------------------------------------------
  * core/optimizer.py:7-10 upres_scene / core/grid.py:318-330 upres_volume: trilinear resampling of a

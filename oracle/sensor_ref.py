@@ -89,3 +89,47 @@ def generate_sensor_backward(x, v, e, p, n, res, span, grad_img, tangent=None, d
     gx = gxp - n[None, :] * ((v * gxp).sum(-1) / den)[:, None]      # (I - v n^T/den)^T gxp
     gv = t[:, None] * gx + (G * np.asarray(e, dtype=dtype) * np.sign(den))[:, None] * n[None, :]
     return gx, gv
+
+
+def _ang_cut(angle_span):
+    return np.sin(0.5 * np.deg2rad(float(angle_span)))               # sensor.py:38
+
+
+def generate_inf_sensor(v, e, n, res, angle_span=120.0, tangent=None, dtype=np.float64):
+    """core/sensor.py:31-53 generate_inf_sensor -> image (res,res): the normalised directions in the sensor frame
+    + ang_cut, Grid(zeros, 2*ang_cut/res).Splat(vn, e, average=False)."""
+    v = np.asarray(v, dtype=dtype)
+    t1, t2 = (a.astype(dtype) for a in tan_vecs(n, tangent))
+    ac = _ang_cut(angle_span)
+    vh = v / np.linalg.norm(v, axis=-1, keepdims=True)                 # :36
+    vn = np.stack([vh @ t1, vh @ t2], -1) + ac                         # :46-47
+    hs, ia, ib, da, db, r, w, valid = _taps(vn, res, 2 * ac)
+    we = w / w.sum(axis=(1, 2), keepdims=True)
+    f = np.asarray(e, dtype=dtype) * np.ones(len(v), dtype=dtype)      # :49
+    img = np.zeros((res, res), dtype=dtype)
+    np.add.at(img, (ia[valid], ib[valid]), (we * f[:, None, None])[valid])
+    return img
+
+
+def generate_inf_sensor_backward(v, e, n, res, grad_img, angle_span=120.0, tangent=None, dtype=np.float64):
+    """Analytic gradient of sum(grad_img * image) w.r.t. v through generate_inf_sensor."""
+    v = np.asarray(v, dtype=dtype)
+    gI = np.asarray(grad_img, dtype=dtype)
+    t1, t2 = (a.astype(dtype) for a in tan_vecs(n, tangent))
+    ac = _ang_cut(angle_span)
+    nv = np.linalg.norm(v, axis=-1, keepdims=True)
+    vh = v / nv
+    vn = np.stack([vh @ t1, vh @ t2], -1) + ac
+    hs, ia, ib, da, db, r, w, valid = _taps(vn, res, 2 * ac)
+    W = w.sum(axis=(1, 2))
+    F = np.asarray(e, dtype=dtype) * np.ones(len(v), dtype=dtype)
+    g = np.where(valid, gI[np.clip(ia, 0, res - 1), np.clip(ib, 0, res - 1)], 0.0)
+    G = (g * w).sum(axis=(1, 2)) / W
+    live = (w > 0) & (r > 0)
+    rs = np.where(r > 0, r, 1.0)
+    dwa = np.where(live, -da / rs, 0.0)
+    dwb = np.where(live, -db / rs, 0.0)
+    ga = (F / W) * ((g * dwa).sum(axis=(1, 2)) - G * dwa.sum(axis=(1, 2))) / hs
+    gb = (F / W) * ((g * dwb).sum(axis=(1, 2)) - G * dwb.sum(axis=(1, 2))) / hs
+    gp = ga[:, None] * t1[None, :] + gb[:, None] * t2[None, :]        # dL/d vhat
+    return (gp - vh * (vh * gp).sum(-1, keepdims=True)) / nv          # (I - vh vh^T)/|v|

@@ -26,6 +26,9 @@ helpers -- plus the CPU oracle:
   sensor_splat.npz     core/sensor.py generate_sensor (:5-28) and torch.autograd through it, RUN AS IS in
                        float64 -> pins the sensor image splat and its backward
 
+  sensor_far.npz       core/sensor.py generate_inf_sensor (:31-53) and torch.autograd through it, RUN AS IS in float64
+                       -> pins the far-field sensor (core/image_opt.py:116)
+
   upres.npz            core/optimizer.py upres_scene (:7-10) RUN AS IS -> pins the multires up-sampling
 
   source_rays.npz      core/source.py rand_rays_cube (:398-412), rand_rays_in_sphere (:352-357, circle and
@@ -238,6 +241,33 @@ def sensor_splat():
     save("sensor_splat.npz", **out)
 
 
+def sensor_far():
+    """core/sensor.py generate_inf_sensor (:31-53) and torch.autograd through it RUN AS IS (float64, CPU): the
+    far-field sensor of core/image_opt.py:116."""
+    torch.manual_seed(4)
+    out = {}
+    for tag, res, with_t, span_deg in (("a", 24, True, 120), ("b", 17, False, 60)):
+        N = 1500
+        x = torch.rand(N, 3, dtype=torch.float64)
+        v = torch.randn(N, 3, dtype=torch.float64) * (0.35 if tag == "a" else 0.2)
+        v[:, 1] = 1.0
+        v = v * (0.8 + 0.7 * torch.rand(N, 1, dtype=torch.float64))          # |v| = n != 1 behind a lens
+        p = torch.tensor([[0.5, 1.2, 0.5]], dtype=torch.float64)
+        n = torch.tensor([[0.08, 1.0, -0.04]], dtype=torch.float64)
+        n = n / n.norm()
+        t = torch.tensor([[0.0, 0.0, 1.0]], dtype=torch.float64) if with_t else None
+        v.requires_grad_(True)
+        e = 1 if tag == "a" else 0.7
+        img = ref_sensor.generate_inf_sensor((x, v), e, (p, n), res, span_deg, t)
+        gI = torch.randn_like(img)
+        (img * gI).sum().backward()
+        out.update({f"{tag}_x": x.numpy(), f"{tag}_v": v.detach().numpy(), f"{tag}_e": np.asarray(float(e)),
+                    f"{tag}_p": p.numpy(), f"{tag}_n": n.numpy(), f"{tag}_t": (t.numpy() if with_t else np.zeros((0, 3))),
+                    f"{tag}_res": res, f"{tag}_angle_span": span_deg, f"{tag}_img": img.detach().numpy(),
+                    f"{tag}_gI": gI.numpy(), f"{tag}_gv": v.grad.numpy()})
+    save("sensor_far.npz", **out)
+
+
 def source_rays():
     """core/source.py generators RUN AS IS; `u_*` are the uniforms they drew (same seed replayed)."""
     out = {}
@@ -297,5 +327,6 @@ if __name__ == "__main__":
     ad_vs_adjoint()
     fuel_injection()
     sensor_splat()
+    sensor_far()
     upres()
     source_rays()

@@ -147,3 +147,62 @@ def test_hip_sensor_fuzz(gpu, seed):
     (img * f(gI)).sum().backward()
     gx, gv = S.generate_sensor_backward(x32, v32, e32, p32, n32, res, span, gI.astype(np.float32).astype(np.float64), t32)
     assert cases.rel_l2(xs.grad.cpu().numpy(), gx) <= 1e-2 and cases.rel_l2(vs.grad.cpu().numpy(), gv) <= 1e-2
+
+
+# ---------------------------------------------------------------------------------------- far-field sensor
+GF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sensor_far.npz")
+
+
+def _far_case(z, tag):
+    t = z[f"{tag}_t"]
+    return dict(x=z[f"{tag}_x"], v=z[f"{tag}_v"], e=float(z[f"{tag}_e"]), p=z[f"{tag}_p"], n=z[f"{tag}_n"],
+                t=(t if t.size else None), res=int(z[f"{tag}_res"]), angle_span=float(z[f"{tag}_angle_span"]),
+                img=z[f"{tag}_img"], gI=z[f"{tag}_gI"], gv=z[f"{tag}_gv"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_far_restatement_matches_reference_run(tag):
+    """core/sensor.py:31-53 generate_inf_sensor RUN AS IS (fixture) vs the numpy restatement, forward and backward."""
+    from oracle import sensor_ref as S
+    c = _far_case(np.load(GF), tag)
+    img = S.generate_inf_sensor(c["v"], c["e"], c["n"], c["res"], c["angle_span"], c["t"])
+    assert np.abs(img - c["img"]).max() < 1e-6 * max(1.0, np.abs(c["img"]).max())    # the reference mixes f32 `fe` into f64
+    gv = S.generate_inf_sensor_backward(c["v"], c["e"], c["n"], c["res"], c["gI"], c["angle_span"], c["t"])
+    assert cases.rel_l2(gv, c["gv"]) < 1e-6
+    assert c["img"].sum() > 0.5 * c["e"] * len(c["v"])               # most directions fall inside the angular window
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_far_sensor_matches_reference_run(gpu, tag):
+    from adjointnonlinearraytracing_amd import sensor
+    c = _far_case(np.load(GF), tag)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu, torch.float32)
+    x, v = f(c["x"]).requires_grad_(True), f(c["v"]).requires_grad_(True)
+    t = None if c["t"] is None else f(c["t"])
+    img = sensor.generate_inf_sensor((x, v), c["e"], (f(c["p"]), f(c["n"])), c["res"], c["angle_span"], t)
+    assert img.shape == (c["res"], c["res"])
+    assert cases.rel_l2(img.detach().cpu().numpy(), c["img"]) <= 5e-6
+    (img * f(c["gI"])).sum().backward()
+    assert x.grad is None or float(x.grad.abs().sum()) == 0.0        # positions do not enter (sensor.py:33)
+    assert cases.rel_l2(v.grad.cpu().numpy(), c["gv"]) <= 3e-4       # fp32 tent-weight derivatives
+
+
+@pytest.mark.gpu
+def test_hip_far_sensor_full_size(gpu):
+    """1M directions onto a 512^2 far-field image (config 5 shape): conservation + the restatement on a sub-sample."""
+    from adjointnonlinearraytracing_amd import sensor
+    from oracle import sensor_ref as S
+    torch.manual_seed(1)
+    n, res = 1 << 20, 512
+    x = torch.rand(n, 3, device=gpu)
+    v = torch.randn(n, 3, device=gpu) * 0.15
+    v[:, 1] = 1.0
+    p = torch.tensor([[0.5, 1.1, 0.5]], device=gpu); nn = torch.tensor([[0.0, 1.0, 0.0]], device=gpu)
+    tt = torch.tensor([[0.0, 0.0, 1.0]], device=gpu)
+    img = sensor.generate_inf_sensor((x, v), 1, (p, nn), res, 120, tt)
+    assert abs(float(img.double().sum()) - n) <= 1e-4 * n            # every direction is inside +-60 degrees here
+    sub = slice(0, 20000)
+    img_s = sensor.generate_inf_sensor((x[sub], v[sub]), 1, (p, nn), res, 120, tt)
+    ref = S.generate_inf_sensor(v[sub].cpu().numpy(), 1.0, nn.cpu().numpy(), res, 120, tt.cpu().numpy())
+    assert cases.rel_l2(img_s.cpu().numpy(), ref) <= 1e-4
