@@ -377,15 +377,20 @@ DRRT_HD void adj_init(const Vol& V, float ds, float dxx, float dxy, float dxz,
   s.outside = false;
 }
 
+// One adjoint iteration is split in two halves so that the windowed kernel can issue the NEXT sample's gather
+// between them (software pipelining, drrt_kernels.hip k_backtrace_win); adj_step below is the plain sequence.
+struct AdjSample { float n, gx, gy, gz, hxy, hxz, hyz; };   // n, grad n (scaled by 1/h), mixed partials (raw)
+
+// First half (src/tracer.cpp:421-425; sdf :488-497): sample the cell `c` the ray has just stepped into (taps `t`),
+// update v, decide whether the ray is still active.  Everything on the march's critical path is here.
 template <int MODE>   // 0 = backtrace, 1 = backtrace_sdf
-DRRT_HD bool adj_step(const Vol& V, const float* __restrict__ sdf, float ds, float grad_scale,
-                      AdjState& s, Cell& c, Corners& w) {
-  s.x = fmaf(-ds, s.vx, s.x); s.y = fmaf(-ds, s.vy, s.y); s.z = fmaf(-ds, s.vz, s.z);   // :420
-  c = locate(V, s.x, s.y, s.z);
-  const Sample q = interp<true>(fetch_vol(V, c), c.wx, c.wy, c.wz);                    // :421-422
-  const float n = q.n, gx = q.gx * V.inv_h, gy = q.gy * V.inv_h, gz = q.gz * V.inv_h;
-  const float mdsn = -ds * n;
-  s.vx = fmaf(mdsn, gx, s.vx); s.vy = fmaf(mdsn, gy, s.vy); s.vz = fmaf(mdsn, gz, s.vz); // :423
+DRRT_HD bool adj_sample(const Vol& V, const float* __restrict__ sdf, float ds, AdjState& s, const Cell& c, const Taps& t,
+                        AdjSample& m) {
+  const Sample q = interp<true>(t, c.wx, c.wy, c.wz);                                  // :421-422
+  m.n = q.n; m.gx = q.gx * V.inv_h; m.gy = q.gy * V.inv_h; m.gz = q.gz * V.inv_h;
+  m.hxy = q.hxy; m.hxz = q.hxz; m.hyz = q.hyz;
+  const float mdsn = -ds * m.n;
+  s.vx = fmaf(mdsn, m.gx, s.vx); s.vy = fmaf(mdsn, m.gy, s.vy); s.vz = fmaf(mdsn, m.gz, s.vz); // :423
   bool active = true;
   if (!c.interior) active = !escaped(V, s.x, s.y, s.z, -s.vx, -s.vy, -s.vz);            // :425
   if (MODE == 1) {                                                                      // :488-497
@@ -394,12 +399,19 @@ DRRT_HD bool adj_step(const Vol& V, const float* __restrict__ sdf, float ds, flo
     s.outside = now_out;
   }
   s.active = active;
-  if (!active) return false;                                                            // :426-428
+  return active;
+}
+
+// Second half (:430-435), for a ray that is still active: its contribution `w` to dL/dn at the 8 taps of `c`, then
+// the lambda / mu recurrences.  Nothing here feeds the next sample's position.
+DRRT_HD void adj_contrib(const Vol& V, float ds, float grad_scale, AdjState& s, const Cell& c, const AdjSample& m,
+                         Corners& w) {
+  const float n = m.n, gx = m.gx, gy = m.gy, gz = m.gz;
   const float dn = dot3(s.mx, s.my, s.mz, gx, gy, gz);                                  // :430
   const float nds = (n * ds) * grad_scale;
   w = splat_weights(c.wx, c.wy, c.wz, dn * ds, nds * s.mx, nds * s.my, nds * s.mz);     // :431-432
   // la += ds*(dn*grad n + n*H*mu), H = mixed partials / h^2, zero diagonal (:434, Q10)
-  const float hxy = q.hxy * V.inv_h2, hxz = q.hxz * V.inv_h2, hyz = q.hyz * V.inv_h2;
+  const float hxy = m.hxy * V.inv_h2, hxz = m.hxz * V.inv_h2, hyz = m.hyz * V.inv_h2;
   const float hmx = fmaf(hxz, s.mz, hxy * s.my);
   const float hmy = fmaf(hyz, s.mz, hxy * s.mx);
   const float hmz = fmaf(hyz, s.my, hxz * s.mx);
@@ -407,6 +419,16 @@ DRRT_HD bool adj_step(const Vol& V, const float* __restrict__ sdf, float ds, flo
   s.ly = fmaf(ds, fmaf(dn, gy, n * hmy), s.ly);
   s.lz = fmaf(ds, fmaf(dn, gz, n * hmz), s.lz);
   s.mx = fmaf(ds, s.lx, s.mx); s.my = fmaf(ds, s.ly, s.my); s.mz = fmaf(ds, s.lz, s.mz);   // :435
+}
+
+template <int MODE>   // 0 = backtrace, 1 = backtrace_sdf
+DRRT_HD bool adj_step(const Vol& V, const float* __restrict__ sdf, float ds, float grad_scale,
+                      AdjState& s, Cell& c, Corners& w) {
+  s.x = fmaf(-ds, s.vx, s.x); s.y = fmaf(-ds, s.vy, s.y); s.z = fmaf(-ds, s.vz, s.z);   // :420
+  c = locate(V, s.x, s.y, s.z);
+  AdjSample m;
+  if (!adj_sample<MODE>(V, sdf, ds, s, c, fetch_vol(V, c), m)) return false;            // :426-428
+  adj_contrib(V, ds, grad_scale, s, c, m, w);
   return true;
 }
 

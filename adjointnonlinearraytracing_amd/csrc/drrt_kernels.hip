@@ -22,7 +22,6 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
-#include <stdlib.h>
 
 #include <hip/hip_fp16.h>
 
@@ -584,7 +583,26 @@ __device__ __forceinline__ bool shift_emit4(const WinCtx& W, int cx, int cy, int
 
 // ABL = true compiles the development ablations and debug counters in (DRRT_FLAG_DEBUG_COUNTERS or ablation
 // bits set); the product instantiation has neither in its loop.
-template <int MODE, bool ABL = false>
+// The ONE gather site of the pipelined loop: the four pair loads of a strictly interior cell, unless the lane
+// already holds that cell's taps.  (A single load site with loop-carried destination registers keeps the
+// compiler's s_waitcnt at the first USE of the taps, i.e. at the top of the next iteration.)
+__device__ __forceinline__ void prefetch_taps(const Vol& V, const Cell& cn, TapCache& tc) {
+  if (!cn.interior) { tc.base = -1; return; }
+  if (cn.base == tc.base) return;
+  __builtin_assume(cn.base >= 0 && cn.base < (1 << 29));
+  const float* p = V.data + (unsigned)cn.base;
+  tc.t.a = ld_pair(p); tc.t.b = ld_pair(p + V.sy); tc.t.e = ld_pair(p + V.sz); tc.t.f = ld_pair(p + V.sz + V.sy);
+  tc.base = cn.base;
+}
+
+// PIPE = true (the product default): the loop is software-pipelined.  The march's critical path is
+//   taps(x_k) -> n, grad n -> v_k -> x_{k+1} -> taps(x_{k+1}) -> ...
+// while the gradient bookkeeping of step k (8 splat weights, lambda / mu, register accumulation, face emission,
+// LDS adds) only CONSUMES (n, grad n, H) of step k.  So each iteration samples, updates v, steps to x_{k+1} and
+// issues THAT cell's gather first -- skipping it when the ray stays in its cell (fetch_reuse) -- and only then does
+// the bookkeeping of step k, under the gather's latency.  Same per-ray arithmetic (adj_sample / adj_contrib), same
+// emission order, so the results equal the unpipelined loop's.
+template <int MODE, bool ABL = false, bool PIPE = true>
 __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
   __shared__ win_t s_win[kWavesPerBlock][kWinFloats];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
@@ -620,12 +638,39 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
   const int experiment = ABL ? a.experiment : 0;
   unsigned long long* const dbg = ABL ? a.dbg : nullptr;
 
+  // PIPE: cell of the sample the ray stands on + its taps (gather already issued)
+  Cell cn;
+  cn.base = 0; cn.ix = cn.iy = cn.iz = 0; cn.ox = cn.oy = cn.oz = 0; cn.wx = cn.wy = cn.wz = 0.f; cn.interior = false;
+  TapCache tc;
+  tc.base = -1; tc.t = taps_zero();
+  if (PIPE && s.active) {
+    s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);   // :420, first sample
+    cn = locate(V, s.x, s.y, s.z);
+    prefetch_taps(V, cn, tc);
+  }
+
   for (int it = 0; it < a.max_steps; ++it) {
     if (!__any(s.active | acc_valid)) break;                                  // wave-uniform exit
     Cell c; Corners w;
     c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0;
     bool contrib = false;
-    if (s.active) {
+    if (PIPE) {
+      AdjSample m;
+      if (s.active) {
+        c = cn;
+        if (!c.interior) tc.t = fetch(V.data, c);      // boundary cell (clamped neighbours): fetched here, not ahead
+        contrib = adj_sample<MODE>(V, a.sdf, a.ds, s, c, tc.t, m);
+        if (contrib) {
+          ++steps;
+          // step to the next sample and issue its gather now; nothing below depends on it (it + 1 == max_steps: the
+          // extra sample is located and fetched but never used -- locate() clamps, so the addresses are valid)
+          s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);   // :420
+          cn = locate(V, s.x, s.y, s.z);
+          prefetch_taps(V, cn, tc);
+          adj_contrib(V, a.ds, a.grad_scale, s, c, m, w);
+        }
+      }
+    } else if (s.active) {
       contrib = adj_step<MODE>(V, a.sdf, a.ds, a.grad_scale, s, c, w);
       if (contrib) ++steps;
     }
@@ -1027,38 +1072,6 @@ static int maybe_sort(const Vol& V, float h, size_t n, const void* pos, const vo
 
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-// ---- spreading small grids over the whole chip -------------------------------------------------------------
-// A march kernel admits several 256-thread blocks per CU (forward: 8 by registers; adjoint: 4 by its 34 KiB of LDS
-// windows), and the dispatcher fills a CU to that limit before it moves on: a grid of 512 blocks -- one rank's shard
-// of the 1M-ray workload at 8 GPUs -- then occupies a quarter to a half of the 256 CUs and runs 2-3x longer than
-// its share of the work (measured: 131072 rays, forward 0.59 ms / adjoint 1.51 ms against 0.19 / 0.69 ms for an
-// eighth of the full launch).  The only occupancy knob a launch has is its LDS size, so grids that cannot fill the
-// chip anyway ask for enough (unused) dynamic LDS that at most ceil(blocks / CUs) blocks fit one CU.
-static int device_cus() {
-  static int cus[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (!cus[dev]) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cus[dev] = v;
-  }
-  return cus[dev];
-}
-
-static size_t spread_lds_bytes(unsigned blocks, size_t static_lds, unsigned natural_blocks_per_cu) {
-  static const int off = [] { const char* e = getenv("DRRT_DEV_NO_SPREAD"); return (e && e[0] == '1') ? 1 : 0; }();
-  if (off || blocks == 0) return 0;
-  const unsigned cus = (unsigned)device_cus();
-  const unsigned want = (blocks + cus - 1) / cus;                  // blocks per CU if spread evenly
-  if (want >= natural_blocks_per_cu) return 0;                       // the grid fills the chip as it is
-  const size_t kLds = 160 * 1024;
-  size_t per_block = (kLds / want) & ~(size_t)511;                   // floor(160 KiB / per_block) == want blocks fit one CU
-  if (per_block > 64 * 1024) per_block = 64 * 1024;                  // a block's LDS above 64 KiB needs an opt-in attribute;
-                                                                     // 64 KiB already caps a CU at 2 blocks
-  return per_block > static_lds ? per_block - static_lds : 0;
-}
-
 template <int MODE>
 static int run_trace(const float* rif, const float* sdf, long long nvox, const int res[3], size_t n,
                      const void* pos, const void* vel, const float* pln_o, const float* pln_d,
@@ -1104,13 +1117,12 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
     ProfScope prof(DRRT_PROF_TRACE, s);
     if (MODE == 2 || !(flags & DRRT_FLAG_LDS_BRICKS)) {
       const unsigned reuse = (flags & DRRT_FLAG_TAP_REUSE_MASK);
-      const size_t pad = spread_lds_bytes(grid_for(n), 64, 8);
       if (reuse == DRRT_FLAG_TAP_REUSE_OFF)
-        hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(grid_for(n)), dim3(kBlock), pad, s, a);
+        hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
       else if (reuse == DRRT_FLAG_TAP_REUSE_FACE)
-        hipLaunchKernelGGL((k_trace<MODE, 2>), dim3(grid_for(n)), dim3(kBlock), pad, s, a);
+        hipLaunchKernelGGL((k_trace<MODE, 2>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
       else
-        hipLaunchKernelGGL((k_trace<MODE, 1>), dim3(grid_for(n)), dim3(kBlock), pad, s, a);
+        hipLaunchKernelGGL((k_trace<MODE, 1>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
     }
     else
       hipLaunchKernelGGL(k_trace_win<(MODE == 2 ? 0 : MODE)>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
@@ -1228,10 +1240,11 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
     if (flags & DRRT_FLAG_DIRECT_ATOMICS)
       hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
     else if (a.experiment != 0 || a.dbg != nullptr)
-      hipLaunchKernelGGL((k_backtrace_win<MODE, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_backtrace_win<MODE, true, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    else if (flags & DRRT_FLAG_NO_PIPELINE)
+      hipLaunchKernelGGL((k_backtrace_win<MODE, false, false>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
     else
-      hipLaunchKernelGGL((k_backtrace_win<MODE, false>), dim3(grid_for(n)), dim3(kBlock),
-                         spread_lds_bytes(grid_for(n), sizeof(win_t) * kWavesPerBlock * kWinFloats + 64, 4), s, a);
+      hipLaunchKernelGGL((k_backtrace_win<MODE, false, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
   }
   LAUNCH_CHECK("k_backtrace");
   return DRRT_OK;

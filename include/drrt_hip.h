@@ -77,6 +77,8 @@ extern "C" {
 #define DRRT_FLAG_TAP_REUSE_OFF  0x10000u /*   gather all 8 taps at every step                                              */
 #define DRRT_FLAG_TAP_REUSE_FACE 0x20000u /*   also keep the shared face across a y- or z-move (2 pair loads instead of 4)  */
                                           /*   default (0): skip the gather while the ray stays in the same cell            */
+#define DRRT_FLAG_NO_PIPELINE 0x40000u    /* backtrace / backtrace_sdf (A-B measurement; same results): the window kernel's
+                                             loop without software pipelining (sample, bookkeeping, then step) */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
                                        written to the last 512 bytes of the workspace:
                                        [0] LDS-window flushes, [1] ray-steps accumulated through
