@@ -24,6 +24,9 @@ FLAG_DEBUG_COUNTERS = 16
 FLAG_LDS_BRICKS = 32
 FLAG_QUAD_GRID = 64
 FLAG_QUAD_REUSE = 128
+FLAG_TAP_REUSE_OFF, FLAG_TAP_REUSE_FACE = 0x10000, 0x20000
+FLAG_NO_PIPELINE = 0x40000
+FLAG_FLAT_ADJOINT = 0x80000
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
 
@@ -63,6 +66,7 @@ SIGNATURES = {
     "drrt_upres_volume_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "drrt_gen_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "drrt_gen_rays_f32": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "drrt_gen_cone_rays_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _vp, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drrt_last_order": (_vp, [_vp]),
     "drrt_set_order_hint": (None, [_vp, _sz]),
     "drrt_order_hint_pending": (_sz, []),

@@ -762,6 +762,255 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_backtrace_flat: the same adjoint march and the same window scheme as k_backtrace_win<0>, reorganised around ONE
+// invariant -- the lane's register accumulators always belong to the cell the ray stands on -- so that the hot loop
+// carries no second cell, no "accumulator cell" bookkeeping and no per-step window test:
+//
+//   top      taps(x_k) arrive (gather issued one iteration earlier) -> n, grad n, H -> v_k -> still active?
+//            8 splat weights of step k (they need the in-cell fractions of cell k) -> accumulators += weights
+//   step     x_{k+1} = x_k - ds v_k ; locate its cell IN PLACE (the fractions of cell k are dead by now) ;
+//            issue its gather unless the ray stays in its cell
+//   then     lambda / mu recurrences (under the gather)
+//   leave    only if the cell changed: the ray LEAVES cell k -- a move across one face hands the four corners left
+//            behind to the LDS window (quad pre-reduced, as before) and carries the shared four; anything else hands
+//            over all eight -- and the window index of the new cell is computed once, here (a miss votes for a
+//            re-anchor).  A ray that ends hands over all eight.
+// Per-ray arithmetic is adj_sample / adj_contrib of drrt_device.h (bit-identical contributions); only the order in
+// which contributions reach the window differs from k_backtrace_win, i.e. the usual fp32 summation-order noise.
+// MODE 0 (backtrace) only; backtrace_sdf keeps k_backtrace_win.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int win_index(int wox, int woy, int woz, int cx, int cy, int cz) {
+  const int lx = cx - wox, ly = cy - woy, lz = cz - woz;
+  const bool in = ((unsigned)lx < (unsigned)(kWinX - 1)) & ((unsigned)ly < (unsigned)(kWinY - 1)) &
+                  ((unsigned)lz < (unsigned)(kWinZ - 1));
+  return in ? lz * kWinSZ + ly * kWinSY + lx : -1;
+}
+
+// all 8 accumulated corners of the regular cell `base` (window slot lidx, or -1: straight to the grid)
+__device__ __forceinline__ bool flat_emit8(win_t* win, float* grad, int sy, int sz, int lidx, int base,
+                                           f2 p00, f2 p10, f2 p01, f2 p11) {
+  if (lidx >= 0) {
+    // quad pre-reduction: when the 4 lanes of a quad hand over the same cell, one lane adds the quad's sums
+    const bool same = quad_same_key(lidx);
+    float v[8] = {p00.x, p00.y, p10.x, p10.y, p01.x, p01.y, p11.x, p11.y};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float qs = quad_sum(v[k]); v[k] = same ? qs : v[k]; }
+    if (!same || (threadIdx.x & 3u) == 0u) {
+      win_t* q = win + lidx;
+      atomicAdd(q, (win_t)v[0]);                     atomicAdd(q + 1, (win_t)v[1]);
+      atomicAdd(q + kWinSY, (win_t)v[2]);            atomicAdd(q + kWinSY + 1, (win_t)v[3]);
+      atomicAdd(q + kWinSZ, (win_t)v[4]);            atomicAdd(q + kWinSZ + 1, (win_t)v[5]);
+      atomicAdd(q + kWinSZ + kWinSY, (win_t)v[6]);   atomicAdd(q + kWinSZ + kWinSY + 1, (win_t)v[7]);
+    }
+    return true;
+  }
+  float* g = grad + base;
+  atomic_add_f32(g, p00.x);            atomic_add_f32(g + 1, p00.y);
+  atomic_add_f32(g + sy, p10.x);       atomic_add_f32(g + sy + 1, p10.y);
+  atomic_add_f32(g + sz, p01.x);       atomic_add_f32(g + sz + 1, p01.y);
+  atomic_add_f32(g + sz + sy, p11.x);  atomic_add_f32(g + sz + sy + 1, p11.y);
+  return false;
+}
+
+template <bool ABL>
+__global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
+  __shared__ win_t s_win[kWavesPerBlock][kWinFloats];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  win_t* win = s_win[wid];
+  for (int k = lane; k < kWinFloats; k += kWave) win[k] = (win_t)0;
+  wave_lds_fence();
+
+  const Vol& V = a.vol;
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  AdjState s;
+  s.x = s.y = s.z = s.vx = s.vy = s.vz = s.lx = s.ly = s.lz = s.mx = s.my = s.mz = 0.f;
+  s.active = false; s.outside = false;
+  size_t i;
+  if (ray_index(a.perm, t, a.n, i)) {
+    Ray3 p = ld3(a.xt, i, a.io_half), u = ld3(a.vt, i, a.io_half), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
+    s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
+    adj_init(V, a.ds, gxv.x, gxv.y, gxv.z, gvv.x, gvv.y, gvv.z, s);
+  }
+  const int experiment = ABL ? a.experiment : 0;
+  int wox = -(1 << 28), woy = -(1 << 28), woz = -(1 << 28);   // window origin (wave-uniform); far away = nothing is inside
+  // the cell the ray stands on: coordinates of corner 000, flat index, regular (no clamped neighbour), window slot
+  Cell c;
+  c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0; c.wx = c.wy = c.wz = 0.f; c.interior = false;
+  bool regular = false;
+  int lidx = -1;
+  TapCache tc;
+  tc.base = -1; tc.t = taps_zero();
+  f2 p00 = f2{0.f, 0.f}, p10 = p00, p01 = p00, p11 = p00;   // accumulators of cell c: x-pairs at (y0,z0) (y1,z0) (y0,z1) (y1,z1)
+  bool miss = false;                                         // the cell just entered lies outside the window
+  if (s.active) {
+    s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);   // :420, first sample
+    c = locate(V, s.x, s.y, s.z);
+    regular = (c.ox == 1) & (c.oy == V.sy) & (c.oz == V.sz);
+    prefetch_taps(V, c, tc);
+    miss = regular;                                          // no window yet
+  }
+  bool dirty = false;
+  int cooldown = 0;
+  unsigned steps = 0;
+  unsigned n_flush = 0;
+
+  for (int it = 0; it < a.max_steps; ++it) {
+    if (!__any(s.active)) break;                                              // wave-uniform exit
+    // ---- (re-)anchor the window around the cells the rays stand on (wave-uniform branch) ----
+    const unsigned long long mm = __ballot(s.active & miss);
+    if (mm != 0ull && cooldown == 0) {
+      if (dirty) { win_flush(win, wox, woy, woz, a.grad, V, lane, experiment == 2); dirty = false; ++n_flush; }
+      const unsigned long long cm = __ballot(s.active & regular);
+      const int first = __ffsll((long long)cm) - 1, last = 63 - __clzll((long long)cm);
+      int ref = (first + last) >> 1;
+      if (!((cm >> ref) & 1ull)) ref = first;
+      const int rx = __shfl(c.ix, ref, kWave), ry = __shfl(c.iy, ref, kWave), rz = __shfl(c.iz, ref, kWave);
+      const float dx_ = -__shfl(s.vx, ref, kWave), dy_ = -__shfl(s.vy, ref, kWave), dz_ = -__shfl(s.vz, ref, kWave);
+      const float inv_dm = 1.0f / fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f));
+      const float fx = 0.5f - 0.35f * (dx_ * inv_dm), fy = 0.5f - 0.35f * (dy_ * inv_dm), fz = 0.5f - 0.35f * (dz_ * inv_dm);
+      int ox = rx - (int)(fx * (float)(kWinX - 2));
+      int oy = ry - (int)(fy * (float)(kWinY - 2));
+      int oz = rz - (int)(fz * (float)(kWinZ - 2));
+      ox = max(0, min(ox, V.W - kWinX)); oy = max(0, min(oy, V.H - kWinY)); oz = max(0, min(oz, V.D - kWinZ));
+      wox = __builtin_amdgcn_readfirstlane(ox); woy = __builtin_amdgcn_readfirstlane(oy);
+      woz = __builtin_amdgcn_readfirstlane(oz);
+      lidx = regular ? win_index(wox, woy, woz, c.ix, c.iy, c.iz) : -1;       // every lane's cell, in the new window
+      miss = s.active & regular & (lidx < 0);
+      cooldown = (__ballot(miss) != 0ull) ? 4 : 0;                            // incoherent wave: do not thrash
+    } else if (cooldown > 0) {
+      --cooldown;
+    }
+    bool used_lds = false;
+    if (s.active) {
+      if (!c.interior) tc.t = fetch(V.data, c);          // boundary cell (clamped neighbours): fetched here, not ahead
+      AdjSample m;
+      if (!adj_sample<0>(V, nullptr, a.ds, s, c, tc.t, m)) {
+        // the ray has ended (:426-428): it contributes nothing here; hand over what its cell has accumulated
+        if (regular && experiment != 1) used_lds = flat_emit8(win, a.grad, V.sy, V.sz, lidx, c.base, p00, p10, p01, p11);
+      } else {
+        ++steps;
+        Corners w;
+        {
+          // first half of adj_contrib: the 8 splat weights (they need the in-cell fractions of THIS cell)
+          const float dn = dot3(s.mx, s.my, s.mz, m.gx, m.gy, m.gz);                            // :430
+          const float nds = (m.n * a.ds) * a.grad_scale;
+          w = splat_weights(c.wx, c.wy, c.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);   // :431-432
+          if (regular) {
+            p00 += f2{w.c000, w.c100}; p10 += f2{w.c010, w.c110}; p01 += f2{w.c001, w.c101}; p11 += f2{w.c011, w.c111};
+          } else if (experiment != 2 && experiment != 1) {
+            // clamped boundary cell: taps coincide; straight to the grid
+            float* g = a.grad + c.base;
+            atomic_add_f32(g, w.c000);                    atomic_add_f32(g + c.ox, w.c100);
+            atomic_add_f32(g + c.oy, w.c010);             atomic_add_f32(g + c.oy + c.ox, w.c110);
+            atomic_add_f32(g + c.oz, w.c001);             atomic_add_f32(g + c.oz + c.ox, w.c101);
+            atomic_add_f32(g + c.oz + c.oy, w.c011);      atomic_add_f32(g + c.oz + c.oy + c.ox, w.c111);
+          }
+          // step to the next sample and issue its gather (it + 1 == max_steps: located and fetched, never used)
+          s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);   // :420
+          const int old_base = c.base, old_lidx = lidx;
+          const bool old_regular = regular;
+          c = locate(V, s.x, s.y, s.z);
+          prefetch_taps(V, c, tc);
+          // second half of adj_contrib: lambda / mu (:434-435)
+          const float hxy = m.hxy * V.inv_h2, hxz = m.hxz * V.inv_h2, hyz = m.hyz * V.inv_h2;
+          const float hmx = fmaf(hxz, s.mz, hxy * s.my);
+          const float hmy = fmaf(hyz, s.mz, hxy * s.mx);
+          const float hmz = fmaf(hyz, s.my, hxz * s.mx);
+          s.lx = fmaf(a.ds, fmaf(dn, m.gx, m.n * hmx), s.lx);
+          s.ly = fmaf(a.ds, fmaf(dn, m.gy, m.n * hmy), s.ly);
+          s.lz = fmaf(a.ds, fmaf(dn, m.gz, m.n * hmz), s.lz);
+          s.mx = fmaf(a.ds, s.lx, s.mx); s.my = fmaf(a.ds, s.ly, s.my); s.mz = fmaf(a.ds, s.lz, s.mz);
+          // ---- the ray leaves its cell ----
+          if (c.base != old_base || !c.interior) {
+            regular = c.interior | ((c.ox == 1) & (c.oy == V.sy) & (c.oz == V.sz));
+            const int d = c.base - old_base;
+            if (d != 0 || regular != old_regular) {
+              const bool ax = (d == 1) | (d == -1), ay = (d == V.sy) | (d == -V.sy), az = (d == V.sz) | (d == -V.sz);
+              if (old_regular) {
+                if (regular & (ax | ay | az) & (experiment != 1) & (experiment != 4)) {
+                  // one face crossed: emit the face left behind, carry the shared one
+                  const bool fwd = d > 0;
+                  // emitted corners e0..e3 and carried ones, in (p, q) in-face order; LDS / grid strides of p, q and of the axis
+                  float e0, e1, e2, e3;
+                  int lp, lq, la, gp, gq, ga;
+                  if (ay) {
+                    const f2 ea = fwd ? p00 : p10, eb = fwd ? p01 : p11;
+                    e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
+                    const f2 ka = fwd ? p10 : p00, kb = fwd ? p11 : p01;
+                    p00 = fwd ? ka : f2{0.f, 0.f}; p01 = fwd ? kb : f2{0.f, 0.f};
+                    p10 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
+                    lp = 1; lq = kWinSZ; la = kWinSY; gp = 1; gq = V.sz; ga = V.sy;
+                  } else if (az) {
+                    const f2 ea = fwd ? p00 : p01, eb = fwd ? p10 : p11;
+                    e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
+                    const f2 ka = fwd ? p01 : p00, kb = fwd ? p11 : p10;
+                    p00 = fwd ? ka : f2{0.f, 0.f}; p10 = fwd ? kb : f2{0.f, 0.f};
+                    p01 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
+                    lp = 1; lq = kWinSY; la = kWinSZ; gp = 1; gq = V.sy; ga = V.sz;
+                  } else {
+                    e0 = fwd ? p00.x : p00.y; e1 = fwd ? p10.x : p10.y; e2 = fwd ? p01.x : p01.y; e3 = fwd ? p11.x : p11.y;
+                    p00 = fwd ? f2{p00.y, 0.f} : f2{0.f, p00.x}; p10 = fwd ? f2{p10.y, 0.f} : f2{0.f, p10.x};
+                    p01 = fwd ? f2{p01.y, 0.f} : f2{0.f, p01.x}; p11 = fwd ? f2{p11.y, 0.f} : f2{0.f, p11.x};
+                    lp = kWinSY; lq = kWinSZ; la = 1; gp = V.sy; gq = V.sz; ga = 1;
+                  }
+                  if (old_lidx >= 0) {
+                    if (experiment != 3) {
+                      const int qi = old_lidx + (fwd ? 0 : la);
+                      // pair / quad pre-reduction (see shift_emit4): lanes of a quad that go to the same four slots
+                      const int key = qi | ((ay ? 1 : (az ? 2 : 0)) << 16);
+                      const int k1 = __builtin_amdgcn_update_dpp(-1, key, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+                      const int k2 = __builtin_amdgcn_update_dpp(-1, key, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+                      const int k3 = __builtin_amdgcn_update_dpp(-1, key, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+                      const bool psame = k1 == key;
+                      const bool same = psame & (k2 == key) & (k3 == key);
+                      float q0 = e0, q1 = e1, q2 = e2, q3 = e3;
+                      q0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, false));
+                      q1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, false));
+                      q2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q2), 0xB1, 0xF, 0xF, false));
+                      q3 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q3), 0xB1, 0xF, 0xF, false));
+                      const float s0 = q0 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q0), 0x4E, 0xF, 0xF, false));
+                      const float s1 = q1 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1), 0x4E, 0xF, 0xF, false));
+                      const float s2 = q2 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q2), 0x4E, 0xF, 0xF, false));
+                      const float s3 = q3 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q3), 0x4E, 0xF, 0xF, false));
+                      const unsigned ql = threadIdx.x & 3u;
+                      const bool add = same ? ql == 0u : (psame ? (ql & 1u) == 0u : true);
+                      if (add) {
+                        win_t* q = win + qi;
+                        atomicAdd(q, (win_t)(same ? s0 : (psame ? q0 : e0)));      atomicAdd(q + lp, (win_t)(same ? s1 : (psame ? q1 : e1)));
+                        atomicAdd(q + lq, (win_t)(same ? s2 : (psame ? q2 : e2))); atomicAdd(q + lq + lp, (win_t)(same ? s3 : (psame ? q3 : e3)));
+                      }
+                    }
+                    used_lds = true;
+                  } else if (experiment != 2) {
+                    float* g = a.grad + old_base + (fwd ? 0 : ga);
+                    atomic_add_f32(g, e0); atomic_add_f32(g + gp, e1); atomic_add_f32(g + gq, e2); atomic_add_f32(g + gq + gp, e3);
+                  }
+                } else {
+                  // jump over more than one face, or into a clamped cell: hand over all eight
+                  if (experiment != 1) used_lds = flat_emit8(win, a.grad, V.sy, V.sz, old_lidx, old_base, p00, p10, p01, p11);
+                  p00 = p10 = p01 = p11 = f2{0.f, 0.f};
+                }
+              }
+              lidx = regular ? win_index(wox, woy, woz, c.ix, c.iy, c.iz) : -1;
+              miss = regular & (lidx < 0);
+            }
+          }
+        }
+      }
+    }
+    dirty = dirty | (__ballot(used_lds) != 0ull);
+  }
+  // rays still marching when max_steps ran out keep what their cell has accumulated: hand it over
+  if (s.active && regular && experiment != 1) { if (flat_emit8(win, a.grad, V.sy, V.sz, lidx, c.base, p00, p10, p01, p11)) dirty = true; }
+  dirty = __ballot(dirty) != 0ull;
+  if (dirty) { win_flush(win, wox, woy, woz, a.grad, V, lane, experiment == 2); ++n_flush; }
+  if (ABL && a.dbg) {
+    if (lane == 0) atomicAdd(&a.dbg[0], (unsigned long long)n_flush);
+  }
+  block_stats(a.stats, steps, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // cable (radial profile) variants, src/tracer.cpp:312-382 and :511-567
 // The profile (<= a few hundred floats) lives in LDS; the adjoint accumulates into an LDS copy
 // of the gradient profile (ds_add_f32) and flushes it once per block -- millions of rays would
@@ -1239,6 +1488,12 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
     ProfScope prof(DRRT_PROF_BACKTRACE, s);
     if (flags & DRRT_FLAG_DIRECT_ATOMICS)
       hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    else if (MODE == 0 && (flags & DRRT_FLAG_FLAT_ADJOINT) && !(flags & DRRT_FLAG_QUAD_GRID)) {
+      if (a.experiment != 0 || a.dbg != nullptr)
+        hipLaunchKernelGGL((k_backtrace_flat<true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      else
+        hipLaunchKernelGGL((k_backtrace_flat<false>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    }
     else if (a.experiment != 0 || a.dbg != nullptr)
       hipLaunchKernelGGL((k_backtrace_win<MODE, true, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
     else if (flags & DRRT_FLAG_NO_PIPELINE)

@@ -43,7 +43,8 @@ struct GenArgs {
   int has_ic;
   int n_views, spp, p0, p1;
   int circle, independent;
-  int kind;                // 0 = plane source (source.py:54-69), 1 = point source (:72-104)
+  int kind;                // 0 = plane source (source.py:54-69), 1 = point source (:72-104), 2 = cone source (:186-203)
+  float cone_cos;          // kind 2: cos(cone_angle / 2), evaluated by the caller in fp32 as hatbox_sample does (:533-534)
   float width, half_width, plane_scale, half_span;
   unsigned cand_per_view, blocks_per_view;
   float* x; float* v; float* planes;
@@ -57,6 +58,11 @@ __device__ __forceinline__ bool gen_point(const GenArgs& a, int view, unsigned c
   const unsigned s = c / pp, rem = c - s * pp;
   const unsigned i = rem / (unsigned)a.p1, j = rem - i * (unsigned)a.p1;
   const float* uv = a.u + (size_t)view * 2u * a.spp * pp;
+  if (a.kind == 2) {                          // cone source: every candidate is a ray; px, pz carry its two uniforms
+    px = uv[c];                               // hatbox_sample's first torch.rand(N): z   (source.py:535)
+    pz = uv[(size_t)a.cand_per_view + c];     // its second: theta                        (:536)
+    return true;
+  }
   const float o0 = uv[(size_t)s * pp + rem] * a.width;                       // source.py:56
   const float o1 = uv[(size_t)(a.spp + s) * pp + rem] * a.width;
   if (a.kind == 1) {                                                         // point source, :73-83
@@ -177,7 +183,21 @@ __global__ void __launch_bounds__(GEN_BLOCK) k_gen_write(GenArgs a) {
     const unsigned rank = block_rank(keep, tot, wave_tot);
     if (keep) {
       float x[3], vray[3] = {vv[0], vv[1], vv[2]};
-      if (a.kind == 1) {
+      if (a.kind == 2) {
+        // hatbox_sample (source.py:531-545) around e_y with basis e_z: t1 = e_z x e_y = -e_x, t2 = t1 x e_y = -e_z,
+        // so the direction is (-cos(theta) s, z, -sin(theta) s) with z uniform in [cos(cone/2), 1), s = sqrt(1 - z^2)
+        const float zc = px * (1.f - a.cone_cos) + a.cone_cos;
+        const float th = 6.283185307179586f * pz;
+        const float sc = sqrtf(1.f - zc * zc);
+        const float d[3] = {-(cosf(th) * sc), zc, -(sinf(th) * sc)};
+        float vr[3];
+        mat3(R, d, vr);                                                      // :192
+        const float o[3] = {0.f, -a.half_width, 0.f};
+        mat3(R, o, x);                                                       // :191
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { x[k] += a.half_width; vray[k] = vr[k]; }
+        if (a.has_ic) mat3(a.ic_rot, vr, vray);
+      } else if (a.kind == 1) {
         // direction (px, width, pz) normalised (:85-89), rotated (:96); origin R (0, -w/2, 0) + w/2 (:94-95)
         const float nrm = sqrtf((px * px + a.width * a.width) + pz * pz);
         const float d[3] = {px / nrm, a.width / nrm, pz / nrm};
@@ -226,14 +246,36 @@ extern "C" size_t drrt_gen_workspace_bytes(int n_views, int spp, int p0, int p1)
   return ((size_t)n_views * bpv + 1) * sizeof(int);
 }
 
+static int gen_rays_impl(int kind, double cone_cos, const float* u, const float* view_rot, int n_views, int spp, int p0, int p1,
+                         double width, double sensor_dist, int circle, int independent,
+                         const float* ic_rot_host, double span, float* x, float* v, float* planes,
+                         int* view_counts, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int drrt_gen_rays_f32(int kind, const float* u, const float* view_rot, int n_views, int spp, int p0, int p1,
                                  double width, double sensor_dist, int circle, int independent,
                                  const float* ic_rot_host, double span, float* x, float* v, float* planes,
                                  int* view_counts, void* workspace, size_t workspace_bytes, void* stream) {
+  if (kind != 0 && kind != 1) return drrt::sensor_fail(DRRT_ERR_ARG, "source kind must be 0 (plane) or 1 (point)");
+  return gen_rays_impl(kind, 1.0, u, view_rot, n_views, spp, p0, p1, width, sensor_dist, circle, independent, ic_rot_host,
+                       span, x, v, planes, view_counts, workspace, workspace_bytes, stream);
+}
+
+extern "C" int drrt_gen_cone_rays_f32(const float* u, const float* view_rot, int n_views, int spp, int p0, int p1,
+                                      double width, double sensor_dist, double cone_cos, const float* ic_rot_host,
+                                      double span, float* x, float* v, float* planes, int* view_counts, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (!(cone_cos >= -1.0 && cone_cos <= 1.0)) return drrt::sensor_fail(DRRT_ERR_ARG, "cone_cos must lie in [-1, 1]");
+  return gen_rays_impl(2, cone_cos, u, view_rot, n_views, spp, p0, p1, width, sensor_dist, 0, 0, ic_rot_host, span, x, v,
+                       planes, view_counts, workspace, workspace_bytes, stream);
+}
+
+static int gen_rays_impl(int kind, double cone_cos, const float* u, const float* view_rot, int n_views, int spp, int p0, int p1,
+                         double width, double sensor_dist, int circle, int independent,
+                         const float* ic_rot_host, double span, float* x, float* v, float* planes,
+                         int* view_counts, void* workspace, size_t workspace_bytes, void* stream) {
   using namespace drrt;
   if (!u || !view_rot || !x || !v || !planes || !view_counts || !workspace)
     return sensor_fail(DRRT_ERR_ARG, "null pointer");
-  if (kind != 0 && kind != 1) return sensor_fail(DRRT_ERR_ARG, "source kind must be 0 (plane) or 1 (point)");
   if (n_views < 1 || n_views > 65535 || spp < 1 || p0 < 1 || p1 < 1) return sensor_fail(DRRT_ERR_ARG, "bad view / pixel counts");
   const unsigned long long cand = (unsigned long long)spp * p0 * p1;
   if (cand * (unsigned long long)n_views >= (1ull << 31)) return sensor_fail(DRRT_ERR_ARG, "too many candidate rays (>= 2^31)");
@@ -248,6 +290,7 @@ extern "C" int drrt_gen_rays_f32(int kind, const float* u, const float* view_rot
   // python scalars of the reference are doubles, rounded to fp32 when they meet an fp32 tensor
   a.width = (float)width; a.half_width = (float)(width / 2.0);
   a.kind = kind;
+  a.cone_cos = (float)cone_cos;
   a.plane_scale = kind == 1 ? (float)(sensor_dist * width)                    // source.py:102
                             : (float)(sensor_dist + width / 2.0);             // source.py:290
   a.half_span = (float)(span / 2.0);

@@ -1,7 +1,8 @@
 """Counterpart of the ray generators of the reference's ``core/source.py`` that feed the march in the
 3-D scripts: ``plane_source3_rand`` (``:54-69``, with ``rotate_pts_to_source`` ``:275-293`` and
 ``rotate_ray3`` ``:303-312``), ``point_source3_rand`` (``:72-104``), ``rand_rays_in_sphere`` (``:352-357``),
-``rand_ptrays_in_sphere`` (``:360-365``), ``rand_rays_cube`` (``:398-412``, plane source) and
+``rand_ptrays_in_sphere`` (``:360-365``), ``cone_source3_rand`` (``:186-203``, with ``hatbox_sample`` ``:531-545``),
+``rand_ptcone_in_sphere`` (``:386-395``), ``rand_rays_cube`` (``:398-412``, plane and cone sources) and
 ``random_rotate_ic`` (``:555-563``).
 
 Same names, argument order and return structure as the reference; the rays are produced ON the
@@ -15,8 +16,8 @@ compaction included) instead of on the host followed by an upload.  Keyword-only
 * ``rotmat``  -- a 3x3 matrix: fuses ``random_rotate_ic`` into the generation (saves a second pass
   over the 15 floats per ray).
 
-The deterministic point source and the cone / area sources (``:29-51``, ``:107-272``) are not on the
-accelerated path: ``rand_rays_cube`` with ``src_type != 'plane'`` raises ``NotImplementedError``.
+The deterministic point source and the area sources (``:29-51``, ``:107-185``, ``:206-272``) are not on the
+accelerated path: ``rand_rays_cube`` with ``src_type == 'point'`` raises ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -50,7 +51,13 @@ def rotate_ray3(x, angle, vert=False):
     return torch.matmul(x, R.T)
 
 
-def _generate(view_mats, pixels, spp, width, circle, sensor_dist, independent, offset, device, rotmat, span, kind=0):
+def _cone_cos(cone_angle) -> float:
+    """cos(cone_angle / 2) evaluated as hatbox_sample does (core/source.py:533-534): a float32 tensor throughout."""
+    return float(torch.cos(torch.deg2rad(torch.tensor(float(cone_angle))) / 2))
+
+
+def _generate(view_mats, pixels, spp, width, circle, sensor_dist, independent, offset, device, rotmat, span, kind=0,
+              cone_angle=100.0):
     """All views of one call through drrt_gen_rays_f32; returns (x, v, planes), nrays."""
     dev = torch.device("cuda" if device is None else device)
     if dev.type != "cuda":
@@ -75,12 +82,18 @@ def _generate(view_mats, pixels, spp, width, circle, sensor_dist, independent, o
         else:
             m = rotmat.detach().cpu().numpy() if isinstance(rotmat, torch.Tensor) else np.asarray(rotmat)
             ic = (C.c_float * 9)(*np.asarray(m, dtype=np.float64).astype(np.float32).reshape(9).tolist())
-        _lib.check(lib.drrt_gen_rays_f32(
-            int(kind), C.c_void_p(u.data_ptr()), C.c_void_p(rots.data_ptr()), nv, spp, p0, p1, float(width), float(sensor_dist),
-            int(bool(circle)), int(bool(independent)), ic, float(span if span is not None else width),
-            C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(planes.data_ptr()),
-            C.c_void_p(counts.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
-            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        tail = (ic, float(span if span is not None else width),
+                C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(planes.data_ptr()),
+                C.c_void_p(counts.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if kind == 2:
+            _lib.check(lib.drrt_gen_cone_rays_f32(
+                C.c_void_p(u.data_ptr()), C.c_void_p(rots.data_ptr()), nv, spp, p0, p1, float(width), float(sensor_dist),
+                _cone_cos(cone_angle), *tail))
+        else:
+            _lib.check(lib.drrt_gen_rays_f32(
+                int(kind), C.c_void_p(u.data_ptr()), C.c_void_p(rots.data_ptr()), nv, spp, p0, p1, float(width),
+                float(sensor_dist), int(bool(circle)), int(bool(independent)), *tail))
         pre = counts.cpu().tolist()               # the one host sync (the reference syncs on its boolean mask too)
     total = pre[-1]
     nrays = [pre[i + 1] - pre[i] for i in range(nv)]
@@ -120,16 +133,40 @@ def rand_ptrays_in_sphere(nviews, im_res, spp, width, angle_span=360, circle=Fal
     return _generate(mats, im_res, spp, width, circle, sensor_dist, False, offset, device, rotmat, span, kind=1)
 
 
+def cone_source3_rand(angle, pixels, spp, width, circle=False, xaxis=False, sensor_dist=1.0, cone_angle=100.0,
+                      *, offset=None, device=None, rotmat=None, span=None):
+    """core/source.py:186-203 -> (x, v, planes): pixels[0]*pixels[1]*spp rays from the point (0, -width/2, 0)
+    (rotated) with directions drawn by hatbox_sample (:531-545) in a cone of full angle ``cone_angle`` -- the source
+    of the fibre experiment (core/fiber_opt.py:131).  ``circle`` is accepted and ignored, as in the reference.
+    ``offset``: the two uniform draws of hatbox_sample, shape (2, N) (z first, then theta)."""
+    iv, _ = _generate([_view_matrix(angle, xaxis)], pixels, spp, width, False, sensor_dist, False,
+                      None if offset is None else offset.reshape(1, -1), device, rotmat, span, kind=2, cone_angle=cone_angle)
+    return iv
+
+
+def rand_ptcone_in_sphere(nviews, im_res, spp, width, angle_span=360, circle=False, xaxis=False, sensor_dist=1.0,
+                          cone_angle=90.0, *, offset=None, device=None, rotmat=None, span=None):
+    """core/source.py:386-395 -> ((x, v, planes), dists, nrays)."""
+    angles = torch.linspace(0, angle_span, nviews + 1)
+    mats = [_view_matrix(angles[i], xaxis) for i in range(nviews)]
+    iv, nrays = _generate(mats, im_res, spp, width, False, sensor_dist, False, offset, device, rotmat, span, kind=2,
+                          cone_angle=cone_angle)
+    return iv, torch.zeros(nviews), nrays
+
+
 def rand_rays_cube(im_res, spp, width, circle=False, src_type='plane', cone_ang=90,
                    *, offset=None, device=None, rotmat=None, span=None):
-    """core/source.py:398-412 (plane source) -> ((x, v, planes), nrays): four views about z, two about x,
-    sensor_dist = 0."""
-    if src_type != 'plane':
-        raise NotImplementedError("only the plane source is generated on the device (core/source.py:399-400)")
+    """core/source.py:398-412 -> ((x, v, planes), nrays): four views about z, two about x, sensor_dist = 0.
+    src_type 'plane' (plane_source3_rand) or anything but 'point' (cone_source3_rand with cone_angle = cone_ang, :402-404);
+    'point' selects the reference's deterministic point_source3, which is not on the device path."""
+    if src_type == 'point':
+        raise NotImplementedError("point_source3 (deterministic point source, core/source.py:401) is not generated on the device")
     angles = torch.linspace(0, 360, 5)
     vangles = torch.tensor([90, -90])
     mats = [_view_matrix(angles[i], False) for i in range(len(angles) - 1)]
     mats += [_view_matrix(va, True) for va in vangles]
+    if src_type != 'plane':
+        return _generate(mats, im_res, spp, width, False, 0.0, False, offset, device, rotmat, span, kind=2, cone_angle=cone_ang)
     return _generate(mats, im_res, spp, width, circle, 0.0, False, offset, device, rotmat, span)
 
 

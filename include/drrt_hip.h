@@ -79,6 +79,7 @@ extern "C" {
                                           /*   default (0): skip the gather while the ray stays in the same cell            */
 #define DRRT_FLAG_NO_PIPELINE 0x40000u    /* backtrace / backtrace_sdf (A-B measurement; same results): the window kernel's
                                              loop without software pipelining (sample, bookkeeping, then step) */
+#define DRRT_FLAG_FLAT_ADJOINT 0x80000u   /* backtrace (development A-B): the reorganised window kernel k_backtrace_flat */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
                                        written to the last 512 bytes of the workspace:
                                        [0] LDS-window flushes, [1] ray-steps accumulated through
@@ -282,6 +283,15 @@ DRRT_API int drrt_gen_rays_f32(int kind, const float* u, const float* view_rot, 
                       double width, double sensor_dist, int circle, int independent,
                       const float* ic_rot, double span, float* x, float* v, float* planes,
                       int* view_counts, void* workspace, size_t workspace_bytes, void* stream);
+/* Cone source: core/source.py:186-203 cone_source3_rand (the fibre experiment's source, core/fiber_opt.py:131) --
+ * spp*p0*p1 rays per view from the point R (0, -width/2, 0) + width/2 with directions drawn by hatbox_sample
+ * (:531-545) in a cone of full angle cone_angle about R e_y.  `u` holds, per view, the two uniform draws of
+ * hatbox_sample: u[view][0][c] for z, u[view][1][c] for theta, c < spp*p0*p1.  cone_cos = cos(cone_angle / 2) as the
+ * reference evaluates it (fp32, :533-534).  No disc mask: every candidate is a ray.                              */
+DRRT_API int drrt_gen_cone_rays_f32(const float* u, const float* view_rot, int n_views, int spp, int p0, int p1,
+                           double width, double sensor_dist, double cone_cos, const float* ic_rot_host, double span,
+                           float* x, float* v, float* planes, int* view_counts, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ---- profiling aid (bench.py; no counterpart in the reference) --------------------------------
  * After drrt_profile_begin(capacity) every march call records a HIP event pair on its stream

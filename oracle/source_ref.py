@@ -87,9 +87,39 @@ def point_view(u, R, pixels, spp, width, circle=False, sensor_dist=1.0):
     return x.astype(F), v.astype(F), planes
 
 
-def views(u, mats, pixels, spp, width, circle=False, sensor_dist=1.0, independent=False, kind="plane"):
+def cone_cos(cone_angle):
+    """cos(cone_angle / 2) as hatbox_sample evaluates it (:533-534): float32 throughout."""
+    import torch
+    return float(torch.cos(torch.deg2rad(torch.tensor(float(cone_angle))) / 2))
+
+
+def cone_view(u, R, pixels, spp, width, sensor_dist=1.0, cone_angle=100.0):
+    """One view of cone_source3_rand (:186-203) with hatbox_sample (:531-545): u (2, N) = its two uniform draws
+    (z, then theta), N = spp*P0*P1 -> x, v, planes (float32)."""
+    n = int(pixels[0]) * int(pixels[1]) * int(spp)
+    u = np.asarray(u, F).reshape(2, n)
+    w, hw = F(width), F(width / 2)
+    dist = F(cone_cos(cone_angle))
+    z = u[0] * (F(1) - dist) + dist                                        # :535
+    theta = F(2 * np.pi) * u[1]                                            # :536
+    scale = np.sqrt(F(1) - z * z)                                          # :537
+    cx, cy = np.cos(theta) * scale, np.sin(theta) * scale                  # :539-540
+    # t1 = e_z x e_y = -e_x, t2 = t1 x e_y = -e_z (:542-543): vel = cx*t1 + cy*t2 + z*e_y
+    vel = np.stack([-cx, z, -cy], axis=-1).astype(F)
+    vdir, tdir = R[:, 1].copy(), R[:, 2].copy()
+    pos = np.tile(np.array([[0.0, -hw, 0.0]], F), (n, 1))
+    x = _rot(pos, R) + hw                                                  # :191
+    v = _rot(vel, R)                                                       # :192
+    plane_x = F(sensor_dist + width / 2) * vdir + hw                       # :198
+    planes = np.broadcast_to(np.stack([plane_x, vdir, tdir])[None], (n, 3, 3)).astype(F).copy()
+    return x.astype(F), v.astype(F), planes
+
+
+def views(u, mats, pixels, spp, width, circle=False, sensor_dist=1.0, independent=False, kind="plane", cone_angle=100.0):
     """Concatenation over views (:352-357 / :360-365 / :398-412): ((x, v, planes), nrays)."""
-    if kind == "point":
+    if kind == "cone":
+        parts = [cone_view(u[i], mats[i], pixels, spp, width, sensor_dist, cone_angle) for i in range(len(mats))]
+    elif kind == "point":
         parts = [point_view(u[i], mats[i], pixels, spp, width, circle, sensor_dist) for i in range(len(mats))]
     else:
         parts = [plane_view(u[i], mats[i], pixels, spp, width, circle, sensor_dist, independent) for i in range(len(mats))]

@@ -29,6 +29,9 @@ helpers -- plus the CPU oracle:
   sensor_far.npz       core/sensor.py generate_inf_sensor (:31-53) and torch.autograd through it, RUN AS IS in float64
                        -> pins the far-field sensor (core/image_opt.py:116)
 
+  cone_rays.npz        core/source.py cone_source3_rand (:186-203) and rand_rays_cube(src_type='cone') RUN AS IS on replayed
+                       draws -> pins the device cone source (core/fiber_opt.py:131)
+
   upres.npz            core/optimizer.py upres_scene (:7-10) RUN AS IS -> pins the multires up-sampling
 
   source_rays.npz      core/source.py rand_rays_cube (:398-412), rand_rays_in_sphere (:352-357, circle and
@@ -313,6 +316,26 @@ def source_rays():
     save("source_rays.npz", **out)
 
 
+def cone_rays():
+    """core/source.py cone_source3_rand (:186-203, hatbox_sample :531-545) and rand_rays_cube(src_type='cone') (:398-412)
+    RUN AS IS; `u_*` are the uniforms hatbox_sample drew (same host-generator seed replayed: two torch.rand(N) per view)."""
+    out = {}
+    pix, spp, width = (9, 7), 3, 4.0
+    n = pix[0] * pix[1] * spp
+    torch.manual_seed(21)
+    out["single_u"] = torch.stack([torch.rand(n), torch.rand(n)]).numpy()
+    torch.manual_seed(21)
+    x, v, pl = ref_source.cone_source3_rand(torch.tensor(35.0), pix, spp, width, sensor_dist=0.7, cone_angle=100.0)
+    out.update(single_x=x.numpy(), single_v=v.numpy(), single_planes=pl.numpy())
+    torch.manual_seed(22)
+    out["cube_u"] = torch.stack([torch.stack([torch.rand(n), torch.rand(n)]) for _ in range(6)]).numpy()
+    torch.manual_seed(22)
+    (x, v, pl), nr = ref_source.rand_rays_cube(pix, spp, width, src_type='cone', cone_ang=60)
+    out.update(cube_x=x.numpy(), cube_v=v.numpy(), cube_planes=pl.numpy(), cube_nrays=np.array(nr),
+               pix=np.array(pix), spp=spp, width=width)
+    save("cone_rays.npz", **out)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     if only:                                   # e.g. `make_golden.py splat_linear hessians_by_autograd`
@@ -328,5 +351,6 @@ if __name__ == "__main__":
     fuel_injection()
     sensor_splat()
     sensor_far()
+    cone_rays()
     upres()
     source_rays()

@@ -185,3 +185,56 @@ def test_hip_source_argument_errors(S):
         S.rand_rays_cube((8, 8), 1, -1.0)
     with pytest.raises(RuntimeError):
         S.plane_source3_rand(0.0, (8, 8), 1, 1.0, device="cpu")
+
+
+# ---------------------------------------------------------------------------------------- cone source
+@pytest.fixture(scope="module")
+def cone_gold():
+    return np.load(os.path.join(G, "cone_rays.npz"))
+
+
+def test_restatement_matches_reference_cone_source(cone_gold, SR):
+    """core/source.py:186-203 cone_source3_rand + hatbox_sample (:531-545) RUN AS IS (fixture) vs the numpy restatement:
+    single view (angle 35 deg, cone 100 deg) and rand_rays_cube(src_type='cone', cone_ang=60)."""
+    g = cone_gold
+    pix, spp, width = tuple(int(p) for p in g["pix"]), int(g["spp"]), float(g["width"])
+    x, v, pl = SR.cone_view(g["single_u"], SR.view_matrix(np.float32(35.0), False), pix, spp, width, sensor_dist=0.7, cone_angle=100.0)
+    _close(x, g["single_x"], ulps(width)); _close(v, g["single_v"], ulps(1.0)); _close(pl, g["single_planes"], ulps(width))
+    # all directions lie inside the cone about R e_y
+    axis = g["single_planes"][0, 1]
+    assert np.all(g["single_v"] @ axis >= np.cos(np.deg2rad(50.0)) - 1e-6)
+    (x, v, pl), nr = SR.views(g["cube_u"], SR.cube_mats(), pix, spp, width, sensor_dist=0.0, kind="cone", cone_angle=60)
+    assert nr == g["cube_nrays"].tolist() == [pix[0] * pix[1] * spp] * 6
+    _close(x, g["cube_x"], ulps(width)); _close(v, g["cube_v"], ulps(1.0)); _close(pl, g["cube_planes"], ulps(width))
+
+
+@pytest.mark.gpu
+def test_hip_cone_source_matches_reference_run(gpu, cone_gold, S):
+    import torch
+    g = cone_gold
+    pix, spp, width = tuple(int(p) for p in g["pix"]), int(g["spp"]), float(g["width"])
+    x, v, pl = S.cone_source3_rand(torch.tensor(35.0), pix, spp, width, sensor_dist=0.7, cone_angle=100.0,
+                                   offset=torch.from_numpy(g["single_u"]), device=gpu)
+    _close(_np(x), g["single_x"], ulps(width)); _close(_np(v), g["single_v"], 4 * ulps(1.0)); _close(_np(pl), g["single_planes"], ulps(width))
+    (x, v, pl), nr = S.rand_rays_cube(pix, spp, width, src_type='cone', cone_ang=60, offset=torch.from_numpy(g["cube_u"]), device=gpu)
+    assert nr == g["cube_nrays"].tolist()
+    _close(_np(x), g["cube_x"], ulps(width)); _close(_np(v), g["cube_v"], 4 * ulps(1.0)); _close(_np(pl), g["cube_planes"], ulps(width))
+    with pytest.raises(NotImplementedError):
+        S.rand_rays_cube(pix, spp, width, src_type='point', device=gpu)
+
+
+@pytest.mark.gpu
+def test_hip_cone_source_full_size_statistics(gpu, S, SR):
+    """Fibre-experiment size (core/fiber_opt.py:131): 1M rays in one call, bit-compared with the restatement on the
+    same draws (cosf / sinf may differ from numpy's by an ulp: 4-ulp tolerance), unit directions inside the cone."""
+    import torch
+    pix, spp, width = (512, 512), 4, 2.0
+    n = pix[0] * pix[1] * spp
+    u = torch.rand(2, n, generator=torch.Generator().manual_seed(3))
+    x, v, pl = S.cone_source3_rand(torch.tensor(0.0), pix, spp, width, sensor_dist=1.0, cone_angle=40.0, offset=u, device=gpu)
+    assert x.shape == (n, 3) and v.shape == (n, 3) and pl.shape == (n, 3, 3)
+    vn = _np(v)
+    assert np.abs(np.linalg.norm(vn, axis=1) - 1.0).max() < 1e-6
+    assert vn[:, 1].min() >= np.cos(np.deg2rad(20.0)) - 1e-6
+    xr, vr, plr = SR.cone_view(u.numpy(), SR.view_matrix(np.float32(0.0), False), pix, spp, width, sensor_dist=1.0, cone_angle=40.0)
+    _close(vn, vr, 4 * ulps(1.0)); _close(_np(x), xr, ulps(width))
