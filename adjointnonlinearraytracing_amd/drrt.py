@@ -32,7 +32,7 @@ class Options:
     check_failed: bool = True     # print "failed to exit all rays" like src/tracer.cpp:89-90 (asynchronously: no host
                                   # sync per call; the message may appear one call late -- see flush_warnings())
     direct_atomics: bool = False  # adjoint: one global atomic per tap (debug / A-B)
-    flat_adjoint: bool = False    # adjoint: the reorganised window kernel (DRRT_FLAG_FLAT_ADJOINT, development A-B)
+    legacy_adjoint: bool = False  # adjoint: the round-1 window kernel instead of k_backtrace_flat (DRRT_FLAG_LEGACY_ADJOINT, A-B)
     lds_bricks: bool = False      # forward: opt-in LDS-staged bricks of the grid (bit-identical; slower on MI355X)
     quad_grid: object = False     # opt-in 16-byte "quad" copy of the grid in the workspace (DRRT_FLAG_QUAD_GRID):
                                   # True, False, or "auto" = when the call does enough ray-steps per voxel to pay
@@ -67,8 +67,8 @@ def _flags(adjoint: bool = False) -> int:
         f |= _lib.FLAG_CORRECTED_H
     if adjoint and options.direct_atomics:
         f |= _lib.FLAG_DIRECT_ATOMICS
-    if adjoint and options.flat_adjoint:
-        f |= _lib.FLAG_FLAT_ADJOINT
+    if adjoint and options.legacy_adjoint:
+        f |= _lib.FLAG_LEGACY_ADJOINT
     if not adjoint and options.lds_bricks:
         f |= _lib.FLAG_LDS_BRICKS
     return f

@@ -79,7 +79,8 @@ extern "C" {
                                           /*   default (0): skip the gather while the ray stays in the same cell            */
 #define DRRT_FLAG_NO_PIPELINE 0x40000u    /* backtrace / backtrace_sdf (A-B measurement; same results): the window kernel's
                                              loop without software pipelining (sample, bookkeeping, then step) */
-#define DRRT_FLAG_FLAT_ADJOINT 0x80000u   /* backtrace (development A-B): the reorganised window kernel k_backtrace_flat */
+#define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace (A-B measurement; same results up to fp32 summation order): the round-1
+                                             window kernel k_backtrace_win instead of the reorganised k_backtrace_flat */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
                                        written to the last 512 bytes of the workspace:
                                        [0] LDS-window flushes, [1] ray-steps accumulated through

@@ -24,11 +24,11 @@ for name, R, n, step_res, sort in (("luneburg33", 33, 6000, 2, True), ("smooth65
     dx = rng.normal(size=pos.shape).astype(np.float32); dv = rng.normal(size=pos.shape).astype(np.float32)
     g = {}
     for flat in (False, True):
-        drrt.options.flat_adjoint = flat
+        drrt.options.legacy_adjoint = not flat
         g[flat] = T.backtrace(t(rif), rif.shape, xt, vt, t(dx), t(dv), h, ds, order=order).cpu().numpy()
         st = drrt.read_stats()
         g[(flat, "steps")] = st["ray_steps"]
-    drrt.options.flat_adjoint = False
+    drrt.options.legacy_adjoint = False
     with O.arith("factored"):
         ob = O.backtrace(rif, rif.shape, xt.cpu().numpy(), vt.cpu().numpy(), dx, dv, h, ds, dtype=np.float32)
     e_old, e_new = cases.rel_l2(g[False], ob["grad"]), cases.rel_l2(g[True], ob["grad"])
