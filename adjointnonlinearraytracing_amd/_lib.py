@@ -27,6 +27,7 @@ FLAG_QUAD_REUSE = 128
 FLAG_TAP_REUSE_OFF, FLAG_TAP_REUSE_FACE = 0x10000, 0x20000
 FLAG_NO_PIPELINE = 0x40000
 FLAG_LEGACY_ADJOINT = 0x80000
+FLAG_LEGACY_FORWARD = 0x100000
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
 

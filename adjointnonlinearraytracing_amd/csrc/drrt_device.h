@@ -268,6 +268,28 @@ DRRT_HD Corners splat_weights(float wx, float wy, float wz, float val, float gx,
   return c;
 }
 
+// The same 8 corner contributions as x-PAIRS (c_0bc, c_1bc), computed with packed fp32 operations (v_pk_mul_f32 /
+// v_pk_fma_f32: two IEEE operations per instruction, the SAME operations in the same order as splat_weights, so the
+// values are bit-identical): 13 packed + 7 scalar instructions instead of 42 scalar ones.
+struct CornerPairs { f2 c00, c10, c01, c11; };    // (y0,z0) (y1,z0) (y0,z1) (y1,z1), each (x0, x1)
+
+DRRT_HD f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+DRRT_HD CornerPairs splat_weights_pk(float wx, float wy, float wz, float val, float gx, float gy, float gz) {
+  const float y0 = 1.f - wy, z0 = 1.f - wz;
+  const f2 X = f2{1.f - wx, wx}, Y = f2{y0, wy};
+  const f2 A = fma2(f2{val, val}, X, f2{-gx, gx});                       // val*X_a -+ gx
+  const f2 yzl = Y * z0, yzh = Y * wz;                                   // (yz00, yz10), (yz01, yz11)
+  const f2 gyz = f2{z0, wz} * gy, gzy = Y * gz;                          // (gyz0, gyz1), (gzy0, gzy1)
+  const float b00 = -gyz.x - gzy.x, b10 = gyz.x - gzy.y, b01 = gzy.x - gyz.y, b11 = gyz.y + gzy.y;
+  CornerPairs c;
+  c.c00 = fma2(f2{yzl.x, yzl.x}, A, X * b00);
+  c.c10 = fma2(f2{yzl.y, yzl.y}, A, X * b10);
+  c.c01 = fma2(f2{yzh.x, yzh.x}, A, X * b01);
+  c.c11 = fma2(f2{yzh.y, yzh.y}, A, X * b11);
+  return c;
+}
+
 // ---------------------------------------------------------------------------------------------
 // one forward march iteration (src/tracer.cpp:68-86; plane :144-145; sdf :287-288)
 // MODE 0 = trace, 1 = trace_plane, 2 = trace_sdf, 3 = trace_target (closest-approach tracking)

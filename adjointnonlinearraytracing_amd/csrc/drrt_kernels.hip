@@ -123,6 +123,87 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
   block_stats(a.stats, steps, failed);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_trace_flat: Tracer::trace (MODE 0) with the loop written out flat -- the same per-step arithmetic as trace_ray /
+// fwd_step_c (drrt_device.h), but the cell is located IN PLACE (nothing but position, fractions, flat index and the
+// 8 taps is carried from step to step), a strictly interior step touches no box test, no masked-zero taps and no
+// clamp offsets, and the gather of the next cell is skipped while the ray stays in its cell.  Boundary cells (the
+// outermost layer, where the clamps and the inbounds / escaped tests matter) take the generic path of drrt_device.h.
+// Bit-identical to k_trace<0> (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_trace_flat(TraceArgs a) {
+  const Vol& V = a.vol;
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  unsigned steps = 0, failed = 0;
+  size_t i;
+  if (ray_index(a.perm, t, a.n, i)) {
+    const Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
+    float x = p.x, y = p.y, z = p.z, vx = u.x, vy = u.y, vz = u.z;
+    float xtx = x, xty = y, xtz = z, vtx = vx, vty = vy, vtz = vz;                       // :56-57
+    bool inside = inbounds(V, x, y, z), esc = false;                                        // :61-62
+    Cell c = locate(V, x, y, z);
+    int base = c.base;
+    float wx = c.wx, wy = c.wy, wz = c.wz;
+    bool interior = c.interior;
+    Taps tp = taps_zero();
+    // the four rows of a cell's taps as wave-uniform base pointers + ONE 32-bit byte offset per lane
+    // (global_load ... saddr: one shift instead of four 64-bit address computations per gather)
+    const char* const d00 = (const char*)V.data;
+    const char* const d10 = d00 + 4u * (unsigned)V.sy;
+    const char* const d01 = d00 + 4u * (unsigned)V.sz;
+    const char* const d11 = d01 + 4u * (unsigned)V.sy;
+    if (interior) {
+      const unsigned off = (unsigned)base << 2;
+      tp.a = ld_pair((const float*)(d00 + off)); tp.b = ld_pair((const float*)(d10 + off));
+      tp.e = ld_pair((const float*)(d01 + off)); tp.f = ld_pair((const float*)(d11 + off));
+    }
+    for (int it = 0; it < a.max_steps; ++it) {
+      if (inside) {                                                                         // masked gather (Q4)
+        if (!interior) {                          // boundary cell: clamp offsets from the position, taps fetched here
+          const Cell cb = locate(V, x, y, z);
+          tp = fetch(V.data, cb);
+        }
+        const Sample q = interp<false>(tp, wx, wy, wz);
+        const float gx = q.gx * V.inv_h, gy = q.gy * V.inv_h, gz = q.gz * V.inv_h;
+        const float dsn = a.ds * q.n;
+        vx = fmaf(dsn, gx, vx); vy = fmaf(dsn, gy, vy); vz = fmaf(dsn, gz, vz);             // :70
+      }
+      x = fmaf(a.ds, vx, x); y = fmaf(a.ds, vy, y); z = fmaf(a.ds, vz, z);                  // :71
+      // locate() in place
+      const float fx = x * V.inv_h, fy = y * V.inv_h, fz = z * V.inv_h;
+      const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+      wx = fx - flx; wy = fy - fly; wz = fz - flz;
+      const int ix = f2i_sat(flx), iy = f2i_sat(fly), iz = f2i_sat(flz);
+      const bool was_interior = interior;
+      interior = (((unsigned)ix - 1u) < V.lx) & (((unsigned)iy - 1u) < V.ly) & (((unsigned)iz - 1u) < V.lz);
+      bool cur_inside = true, esc_now = false;
+      if (interior) {
+        const int nb = mad24(iz, V.sz, mad24(iy, V.sy, ix));
+        if (!(was_interior & (nb == base))) {
+          __builtin_assume(nb >= 0 && nb < (1 << 29));
+          const unsigned off = (unsigned)nb << 2;
+          tp.a = ld_pair((const float*)(d00 + off)); tp.b = ld_pair((const float*)(d10 + off));
+          tp.e = ld_pair((const float*)(d01 + off)); tp.f = ld_pair((const float*)(d11 + off));
+        }
+        base = nb;
+      } else {
+        cur_inside = inbounds(V, x, y, z);                                                  // :73
+        esc_now = escaped(V, x, y, z, vx, vy, vz);                                          // :76
+      }
+      const bool cross = inside & !cur_inside;                                              // :74
+      esc = esc | cross | esc_now;                                                          // :75-76
+      if (cross) { xtx = x; xty = y; xtz = z; vtx = vx; vty = vy; vtz = vz; }               // :79-80
+      inside = cur_inside;                                                                  // :86
+      ++steps;
+      if (esc) break;                                                                       // per-ray form of :82
+    }
+    if (!esc) { xtx = x; xty = y; xtz = z; failed = 1u; }                                   // :95 (vt stays, Q6)
+    st3(a.xt, i, xtx, xty, xtz, a.io_half);
+    st3(a.vt, i, vtx, vty, vtz, a.io_half);
+  }
+  block_stats(a.stats, steps, failed);
+}
+
 // trace_plane / trace_sdf, second pass: rays flagged by the first pass (failmask bit 1 / `again` byte) are
 // re-marched over the reference's GLOBAL loop count (stats->iters of the first pass), see trace_ray / ray_full.
 template <int MODE>
@@ -440,17 +521,28 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // Flush the wave's window into the global grid and leave it zeroed.  Called with all 64 lanes.
+// Lanes are laid out as 4 window rows x 16 x-slots (kWinX <= 16 of them used), so a pass covers 4 (ly, lz) rows and
+// all addresses advance by constants -- no index decoding per slot (the flush runs every ~15 steps of a wave; a flat
+// "k -> (lx, ly, lz)" decode cost ~450 VALU instructions per flush, this one ~180).
 __device__ __forceinline__ void win_flush(win_t* win, int ox, int oy, int oz, float* __restrict__ grad,
                                           const Vol& V, int lane, bool no_global = false) {
+  static_assert(kWinX <= 16, "win_flush maps 16 lanes to one window row");
   wave_lds_fence();
-  for (int k = lane; k < kWinFloats; k += kWave) {
-    // ds_wrxchg_rtn_b64: read the accumulated value and reset the slot in one LDS op
-    win_t v = __hip_atomic_exchange(&win[k], (win_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (v != (win_t)0 && !no_global) {
-      int lx = k % kWinPX, r = k / kWinPX;
-      int ly = r % kWinY, lz = r / kWinY;
-      atomic_add_f32(grad + ((oz + lz) * V.sz + (oy + ly) * V.sy + (ox + lx)), (float)v);
+  const int lx = lane & 15, rsub = lane >> 4;
+  const bool xok = lx < kWinX;
+  win_t* wl = win + rsub * kWinSY + lx;                                  // slot of (lx, ly = rsub, lz = 0)
+  float* gl = grad + ((unsigned)oz * (unsigned)V.sz + (unsigned)(oy + rsub) * (unsigned)V.sy + (unsigned)(ox + lx));
+#pragma unroll 1
+  for (int lz = 0; lz < kWinZ; ++lz) {
+#pragma unroll
+    for (int ly0 = 0; ly0 < kWinY; ly0 += 4) {
+      if (xok & (ly0 + rsub < kWinY)) {
+        // ds_wrxchg_rtn_b64: read the accumulated value and reset the slot in one LDS op
+        const win_t v = __hip_atomic_exchange(wl + ly0 * kWinSY, (win_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (v != (win_t)0 && !no_global) atomic_add_f32(gl + (unsigned)ly0 * (unsigned)V.sy, (float)v);
+      }
     }
+    wl += kWinSZ; gl += V.sz;
   }
   wave_lds_fence();
 }
@@ -590,8 +682,14 @@ __device__ __forceinline__ void prefetch_taps(const Vol& V, const Cell& cn, TapC
   if (!cn.interior) { tc.base = -1; return; }
   if (cn.base == tc.base) return;
   __builtin_assume(cn.base >= 0 && cn.base < (1 << 29));
-  const float* p = V.data + (unsigned)cn.base;
-  tc.t.a = ld_pair(p); tc.t.b = ld_pair(p + V.sy); tc.t.e = ld_pair(p + V.sz); tc.t.f = ld_pair(p + V.sz + V.sy);
+  // the four tap rows as wave-uniform base pointers + ONE 32-bit byte offset per lane (global_load ... saddr)
+  const char* const d00 = (const char*)V.data;
+  const char* const d10 = d00 + 4u * (unsigned)V.sy;
+  const char* const d01 = d00 + 4u * (unsigned)V.sz;
+  const char* const d11 = d01 + 4u * (unsigned)V.sy;
+  const unsigned off = (unsigned)cn.base << 2;
+  tc.t.a = ld_pair((const float*)(d00 + off)); tc.t.b = ld_pair((const float*)(d10 + off));
+  tc.t.e = ld_pair((const float*)(d01 + off)); tc.t.f = ld_pair((const float*)(d11 + off));
   tc.base = cn.base;
 }
 
@@ -868,7 +966,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
       if (!((cm >> ref) & 1ull)) ref = first;
       const int rx = __shfl(c.ix, ref, kWave), ry = __shfl(c.iy, ref, kWave), rz = __shfl(c.iz, ref, kWave);
       const float dx_ = -__shfl(s.vx, ref, kWave), dy_ = -__shfl(s.vy, ref, kWave), dz_ = -__shfl(s.vz, ref, kWave);
-      const float inv_dm = 1.0f / fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f));
+      const float inv_dm = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f)));   // placement only
       const float fx = 0.5f - 0.35f * (dx_ * inv_dm), fy = 0.5f - 0.35f * (dy_ * inv_dm), fz = 0.5f - 0.35f * (dz_ * inv_dm);
       int ox = rx - (int)(fx * (float)(kWinX - 2));
       int oy = ry - (int)(fy * (float)(kWinY - 2));
@@ -896,10 +994,11 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
           // first half of adj_contrib: the 8 splat weights (they need the in-cell fractions of THIS cell)
           const float dn = dot3(s.mx, s.my, s.mz, m.gx, m.gy, m.gz);                            // :430
           const float nds = (m.n * a.ds) * a.grad_scale;
-          w = splat_weights(c.wx, c.wy, c.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);   // :431-432
           if (regular) {
-            p00 += f2{w.c000, w.c100}; p10 += f2{w.c010, w.c110}; p01 += f2{w.c001, w.c101}; p11 += f2{w.c011, w.c111};
+            const CornerPairs cp = splat_weights_pk(c.wx, c.wy, c.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);   // :431-432
+            p00 += cp.c00; p10 += cp.c10; p01 += cp.c01; p11 += cp.c11;
           } else if (experiment != 2 && experiment != 1) {
+            w = splat_weights(c.wx, c.wy, c.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);
             // clamped boundary cell: taps coincide; straight to the grid
             float* g = a.grad + c.base;
             atomic_add_f32(g, w.c000);                    atomic_add_f32(g + c.ox, w.c100);
@@ -1368,7 +1467,9 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
     ProfScope prof(DRRT_PROF_TRACE, s);
     if (MODE == 2 || !(flags & DRRT_FLAG_LDS_BRICKS)) {
       const unsigned reuse = (flags & DRRT_FLAG_TAP_REUSE_MASK);
-      if (reuse == DRRT_FLAG_TAP_REUSE_OFF)
+      if (MODE == 0 && reuse == 0 && !(flags & (DRRT_FLAG_QUAD_GRID | DRRT_FLAG_LEGACY_FORWARD)))
+        hipLaunchKernelGGL(k_trace_flat, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      else if (reuse == DRRT_FLAG_TAP_REUSE_OFF)
         hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
       else if (reuse == DRRT_FLAG_TAP_REUSE_FACE)
         hipLaunchKernelGGL((k_trace<MODE, 2>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);

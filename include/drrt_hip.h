@@ -79,6 +79,7 @@ extern "C" {
                                           /*   default (0): skip the gather while the ray stays in the same cell            */
 #define DRRT_FLAG_NO_PIPELINE 0x40000u    /* backtrace / backtrace_sdf (A-B measurement; same results): the window kernel's
                                              loop without software pipelining (sample, bookkeeping, then step) */
+#define DRRT_FLAG_LEGACY_FORWARD 0x100000u /* trace (A-B measurement; bit-identical results): k_trace<0> instead of k_trace_flat */
 #define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace (A-B measurement; same results up to fp32 summation order): the round-1
                                              window kernel k_backtrace_win instead of the reorganised k_backtrace_flat */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
