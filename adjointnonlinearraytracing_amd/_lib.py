@@ -28,6 +28,7 @@ FLAG_TAP_REUSE_OFF, FLAG_TAP_REUSE_FACE = 0x10000, 0x20000
 FLAG_NO_PIPELINE = 0x40000
 FLAG_LEGACY_ADJOINT = 0x80000
 FLAG_LEGACY_FORWARD = 0x100000
+FLAG_Q16_POS_ONLY = 0x200000
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
 
@@ -53,6 +54,11 @@ SIGNATURES = {
     "drrt_trace_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),
     "drrt_trace_f16io": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),
     "drrt_backtrace_f16io": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
+    "drrt_trace_q16io": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),
+    "drrt_backtrace_q16io": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
+    "drrt_q16_params": (_i, [_vp, _f, _vp]),
+    "drrt_q16_encode": (_i, [_vp, _f, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "drrt_q16_decode": (_i, [_vp, _f, _sz, _vp, _vp, _vp, _vp, _vp]),
     "drrt_trace_pln_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp] + _tail),
     "drrt_trace_target_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp] + _tail),
     "drrt_trace_sdf_f32": (_i, [_vp, _vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),

@@ -42,7 +42,29 @@ struct Vol {
   unsigned lx, ly, lz;  // res-3 (0 when res < 4): a floor index i with 1 <= i <= res-3 is "strictly interior"
   const float4* quad;   // optional (device only): quad[i] = {n[i], n[i+1], n[i+sy], n[i+sy+1]} for every voxel i
                         // (clamped at the far x / y faces), built per call by k_build_quad; null = not in use
+  float q_min, q_step, q_inv_step;   // 16-bit ray-state positions ("q16", include/drrt_hip.h): p = q_min + code * q_step
 };
+
+// ---- 16-bit ray state ("q16"): 6 bytes per 3-vector, like IEEE half, but with the precision where a march needs it ----
+// position  unsigned 16-bit code over [-E/16, E + E/16], E = the largest box extent: step = 1.125 E / 65535 (h/228 on a
+//           256^3 grid, against h/8 for an IEEE half near 1.0); positions outside the range saturate
+// direction signed 16-bit fixed point, step 2^-14 (range [-2, 2): |v| = n stays below 2 for any index below 2)
+// seeds     (dx, dv of the adjoint) stay IEEE half: they need relative, not absolute, precision
+constexpr float kQ16VelStep = 1.0f / 16384.0f;
+DRRT_HD float q16_pos_dec(const Vol& V, uint16_t c) { return fmaf((float)c, V.q_step, V.q_min); }
+DRRT_HD uint16_t q16_pos_enc(const Vol& V, float x) {
+  float t = (x - V.q_min) * V.q_inv_step;
+  t = t > 0.f ? t : 0.f;                       // also NaN -> 0
+  t = t < 65535.f ? t : 65535.f;
+  return (uint16_t)(int)rintf(t);
+}
+DRRT_HD float q16_vel_dec(int16_t c) { return (float)c * kQ16VelStep; }
+DRRT_HD int16_t q16_vel_enc(float v) {
+  float t = v * 16384.0f;
+  t = t > -32768.f ? t : -32768.f;             // also NaN -> -32768
+  t = t < 32767.f ? t : 32767.f;
+  return (int16_t)(int)rintf(t);
+}
 
 DRRT_HD void vol_finish(Vol& V, float h) {   // derived fields; data, W, H, D must be set
   V.sy = V.W; V.sz = V.W * V.H; V.quad = nullptr;
@@ -50,6 +72,8 @@ DRRT_HD void vol_finish(Vol& V, float h) {   // derived fields; data, W, H, D mu
   V.bx = (float)(V.W - 1) * h; V.by = (float)(V.H - 1) * h; V.bz = (float)(V.D - 1) * h;
   V.lx = V.W >= 4 ? (unsigned)(V.W - 3) : 0u; V.ly = V.H >= 4 ? (unsigned)(V.H - 3) : 0u;
   V.lz = V.D >= 4 ? (unsigned)(V.D - 3) : 0u;
+  const float ext = fmaxf(V.bx, fmaxf(V.by, V.bz));
+  V.q_min = -ext * 0.0625f; V.q_step = (ext * 1.125f) / 65535.0f; V.q_inv_step = 65535.0f / (ext * 1.125f);
 }
 
 struct Cell {

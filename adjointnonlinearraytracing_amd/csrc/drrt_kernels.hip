@@ -61,19 +61,48 @@ __device__ __forceinline__ bool ray_index(const uint32_t* __restrict__ perm, siz
 }
 
 struct Ray3 { float x, y, z; };
-// Ray arrays are (n,3) row-major, fp32 or -- for the *_f16io entry points ("fp16 ray state", config 5
-// of BASELINE.json) -- IEEE half.  Half values are widened exactly on load; the march, the adjoint
-// recurrences and the gradient accumulation are always fp32; outputs are rounded to half once.
-__device__ __forceinline__ Ray3 ld3(const void* p, size_t i, int half = 0) {
-  if (half) {
+// Ray arrays are (n,3) row-major in one of three storage formats (`io`): 0 = fp32; 1 = IEEE half (the *_f16io entry
+// points); 2 = the 16-bit ray state "q16" of drrt_device.h (the *_q16io entry points: positions as box-relative
+// unsigned codes, directions as 2^-14 fixed point, adjoint seeds as IEEE half) -- "fp16 ray state", config 5 of
+// BASELINE.json.  Values are widened exactly on load; the march, the adjoint recurrences and the gradient
+// accumulation are always fp32; outputs are rounded to the storage format once.
+enum { RAY_POS = 0, RAY_VEL = 1, RAY_SEED = 2 };
+__device__ __forceinline__ Ray3 ld3(const void* p, size_t i, int io = 0, const Vol* V = nullptr, int kind = RAY_SEED) {
+  if (io == 2 && kind == RAY_POS) {
+    const uint16_t* q = (const uint16_t*)p;
+    return Ray3{q16_pos_dec(*V, q[3 * i]), q16_pos_dec(*V, q[3 * i + 1]), q16_pos_dec(*V, q[3 * i + 2])};
+  }
+  if (io == 3) {                       // q16 positions, everything else fp32
+    if (kind == RAY_POS) {
+      const uint16_t* q = (const uint16_t*)p;
+      return Ray3{q16_pos_dec(*V, q[3 * i]), q16_pos_dec(*V, q[3 * i + 1]), q16_pos_dec(*V, q[3 * i + 2])};
+    }
+    const float* q = (const float*)p;
+    return Ray3{q[3 * i], q[3 * i + 1], q[3 * i + 2]};
+  }
+  if (io == 2 && kind == RAY_VEL) {
+    const int16_t* q = (const int16_t*)p;
+    return Ray3{q16_vel_dec(q[3 * i]), q16_vel_dec(q[3 * i + 1]), q16_vel_dec(q[3 * i + 2])};
+  }
+  if (io) {
     const __half* q = (const __half*)p;
     return Ray3{__half2float(q[3 * i]), __half2float(q[3 * i + 1]), __half2float(q[3 * i + 2])};
   }
   const float* q = (const float*)p;
   return Ray3{q[3 * i], q[3 * i + 1], q[3 * i + 2]};
 }
-__device__ __forceinline__ void st3(void* p, size_t i, float a, float b, float c, int half = 0) {
-  if (half) {
+__device__ __forceinline__ void st3(void* p, size_t i, float a, float b, float c, int io = 0, const Vol* V = nullptr,
+                                    int kind = RAY_SEED) {
+  if ((io == 2 || io == 3) && kind == RAY_POS) {
+    uint16_t* q = (uint16_t*)p;
+    q[3 * i] = q16_pos_enc(*V, a); q[3 * i + 1] = q16_pos_enc(*V, b); q[3 * i + 2] = q16_pos_enc(*V, c);
+  } else if (io == 3) {
+    float* q = (float*)p;
+    q[3 * i] = a; q[3 * i + 1] = b; q[3 * i + 2] = c;
+  } else if (io == 2 && kind == RAY_VEL) {
+    int16_t* q = (int16_t*)p;
+    q[3 * i] = q16_vel_enc(a); q[3 * i + 1] = q16_vel_enc(b); q[3 * i + 2] = q16_vel_enc(c);
+  } else if (io) {
     __half* q = (__half*)p;
     q[3 * i] = __float2half_rn(a); q[3 * i + 1] = __float2half_rn(b); q[3 * i + 2] = __float2half_rn(c);
   } else {
@@ -106,7 +135,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
   unsigned steps = 0, failed = 0;
   size_t i;
   if (ray_index(a.perm, t, a.n, i)) {
-    Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
+    Ray3 p = ld3(a.pos, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vel, i, a.io_half, &a.vol, RAY_VEL);
     const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
     float po[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
     if (MODE == 1) {
@@ -115,8 +144,8 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
     }
     RayOut r = trace_ray<MODE, REUSE>(a.vol, a.sdf, a.ds, a.max_steps, pp, vv, po, pd);
     steps = r.steps; failed = r.act ? 1u : 0u;
-    st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2], a.io_half);
-    st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2], a.io_half);
+    st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2], a.io_half, &a.vol, RAY_POS);
+    st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2], a.io_half, &a.vol, RAY_VEL);
     if (MODE == 1) a.failmask[i] = (r.esc ? 0 : 1) | (r.again ? 2 : 0);     // src/tracer.cpp:171; bit 1: k_trace_again
     if (MODE == 2) a.again[i] = r.again ? 1 : 0;
   }
@@ -137,7 +166,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_flat(TraceArgs a) {
   unsigned steps = 0, failed = 0;
   size_t i;
   if (ray_index(a.perm, t, a.n, i)) {
-    const Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
+    const Ray3 p = ld3(a.pos, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vel, i, a.io_half, &a.vol, RAY_VEL);
     float x = p.x, y = p.y, z = p.z, vx = u.x, vy = u.y, vz = u.z;
     float xtx = x, xty = y, xtz = z, vtx = vx, vty = vy, vtz = vz;                       // :56-57
     bool inside = inbounds(V, x, y, z), esc = false;                                        // :61-62
@@ -198,8 +227,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_flat(TraceArgs a) {
       if (esc) break;                                                                       // per-ray form of :82
     }
     if (!esc) { xtx = x; xty = y; xtz = z; failed = 1u; }                                   // :95 (vt stays, Q6)
-    st3(a.xt, i, xtx, xty, xtz, a.io_half);
-    st3(a.vt, i, vtx, vty, vtz, a.io_half);
+    st3(a.xt, i, xtx, xty, xtz, a.io_half, &a.vol, RAY_POS);
+    st3(a.vt, i, vtx, vty, vtz, a.io_half, &a.vol, RAY_VEL);
   }
   block_stats(a.stats, steps, failed);
 }
@@ -211,7 +240,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_again(TraceArgs a) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.n) return;
   if (MODE == 1 ? !(a.failmask[i] & 2) : !a.again[i]) return;
-  Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
+  Ray3 p = ld3(a.pos, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vel, i, a.io_half, &a.vol, RAY_VEL);
   const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
   float po[3] = {0.f, 0.f, 0.f}, pd[3] = {0.f, 0.f, 0.f};
   if (MODE == 1) {
@@ -219,8 +248,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_again(TraceArgs a) {
     po[0] = o.x; po[1] = o.y; po[2] = o.z; pd[0] = d.x; pd[1] = d.y; pd[2] = d.z;
   }
   RayOut r = ray_full<MODE>(a.vol, a.sdf, a.ds, a.stats->iters, pp, vv, po, pd);
-  st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2], a.io_half);
-  st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2], a.io_half);
+  st3(a.xt, i, r.xt[0], r.xt[1], r.xt[2], a.io_half, &a.vol, RAY_POS);
+  st3(a.vt, i, r.vt[0], r.vt[1], r.vt[2], a.io_half, &a.vol, RAY_VEL);
   if (MODE == 1) a.failmask[i] = r.esc ? 0 : 1;
 }
 
@@ -315,7 +344,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
   bool live = ray_index(a.perm, t, a.n, i);
   const bool mine = live;
   if (live) {
-    Ray3 p = ld3(a.pos, i, a.io_half), u = ld3(a.vel, i, a.io_half);
+    Ray3 p = ld3(a.pos, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vel, i, a.io_half, &a.vol, RAY_VEL);
     s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
     if (MODE == 1) {
       Ray3 o = ld3(a.pln_o, i), d = ld3(a.pln_d, i);
@@ -370,8 +399,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_win(TraceArgs a) {
   if (mine) {
     if (!s.esc) { s.xtx = s.x; s.xty = s.y; s.xtz = s.z; }                  // :95 (vt stays, Q6)
     failed = s.esc ? 0u : 1u;
-    st3(a.xt, i, s.xtx, s.xty, s.xtz, a.io_half);
-    st3(a.vt, i, s.vtx, s.vty, s.vtz, a.io_half);
+    st3(a.xt, i, s.xtx, s.xty, s.xtz, a.io_half, &a.vol, RAY_POS);
+    st3(a.vt, i, s.vtx, s.vty, s.vtz, a.io_half, &a.vol, RAY_VEL);
     // src/tracer.cpp:171; bit 1 = "may record a later exit": re-marched by k_trace_again (same test as trace_ray)
     if (MODE == 1) a.failmask[i] = (s.esc ? 0 : 1) | ((s.esc && plane_again(V, s)) ? 2 : 0);
   }
@@ -456,7 +485,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
   unsigned steps = 0;
   size_t i;
   if (ray_index(a.perm, t, a.n, i)) {
-    Ray3 p = ld3(a.xt, i, a.io_half), u = ld3(a.vt, i, a.io_half), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
+    Ray3 p = ld3(a.xt, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vt, i, a.io_half, &a.vol, RAY_VEL), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
     const float pp[3] = {p.x, p.y, p.z}, vv[3] = {u.x, u.y, u.z};
     const float dxx[3] = {gxv.x, gxv.y, gxv.z}, dvv[3] = {gvv.x, gvv.y, gvv.z};
     float* grad = a.grad;
@@ -714,7 +743,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
   s.active = false;
   size_t i;
   if (ray_index(a.perm, t, a.n, i)) {
-    Ray3 p = ld3(a.xt, i, a.io_half), u = ld3(a.vt, i, a.io_half), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
+    Ray3 p = ld3(a.xt, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vt, i, a.io_half, &a.vol, RAY_VEL), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
     s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
     adj_init(V, a.ds, gxv.x, gxv.y, gxv.z, gvv.x, gvv.y, gvv.z, s);
     if (MODE == 1 && s.active) {                                            // src/tracer.cpp:476-477
@@ -927,7 +956,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
   s.active = false; s.outside = false;
   size_t i;
   if (ray_index(a.perm, t, a.n, i)) {
-    Ray3 p = ld3(a.xt, i, a.io_half), u = ld3(a.vt, i, a.io_half), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
+    Ray3 p = ld3(a.xt, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vt, i, a.io_half, &a.vol, RAY_VEL), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
     s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
     adj_init(V, a.ds, gxv.x, gxv.y, gxv.z, gvv.x, gvv.y, gvv.z, s);
   }
@@ -1501,6 +1530,72 @@ extern "C" int drrt_trace_f16io(const float* rif, long long nvox, const int res[
                       stats, ws, ws_bytes, flags, stream, 1);
 }
 
+extern "C" int drrt_trace_q16io(const float* rif, long long nvox, const int res[3], size_t n,
+                                const void* pos, const void* vel, float h, float ds, void* xt, void* vt,
+                                drrt_stats* stats, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+  return run_trace<0>(rif, nullptr, nvox, res, n, pos, vel, nullptr, nullptr, h, ds, xt, vt, nullptr,
+                      stats, ws, ws_bytes, flags, stream, (flags & DRRT_FLAG_Q16_POS_ONLY) ? 3 : 2);
+}
+
+// ---- 16-bit ray state: encode / decode on the device (so that every binding rounds exactly as the kernels do) ----
+namespace drrt {
+__global__ void __launch_bounds__(256) k_q16_encode(Vol V, size_t n3, const float* __restrict__ pos, const float* __restrict__ vel,
+                                                    uint16_t* __restrict__ pos_q, int16_t* __restrict__ vel_q) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n3) return;
+  if (pos) pos_q[k] = q16_pos_enc(V, pos[k]);
+  if (vel) vel_q[k] = q16_vel_enc(vel[k]);
+}
+__global__ void __launch_bounds__(256) k_q16_decode(Vol V, size_t n3, const uint16_t* __restrict__ pos_q, const int16_t* __restrict__ vel_q,
+                                                    float* __restrict__ pos, float* __restrict__ vel) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n3) return;
+  if (pos_q) pos[k] = q16_pos_dec(V, pos_q[k]);
+  if (vel_q) vel[k] = q16_vel_dec(vel_q[k]);
+}
+}  // namespace drrt
+
+static int q16_vol(const int res[3], float h, Vol* V) {
+  if (!res) return fail(DRRT_ERR_ARG, "null res pointer");
+  if (res[0] < 1 || res[1] < 1 || res[2] < 1) return fail(DRRT_ERR_BAD_RES, "volume: invalid resolution!");
+  if (!(h > 0.f) || !(h < 3.0e38f)) return fail(DRRT_ERR_ARG, "h and ds must be positive and finite");
+  V->data = nullptr; V->W = res[0]; V->H = res[1]; V->D = res[2];
+  vol_finish(*V, h);
+  return DRRT_OK;
+}
+
+extern "C" int drrt_q16_params(const int res[3], float h, float out[3]) {
+  g_err[0] = 0;
+  Vol V; int rc = q16_vol(res, h, &V); if (rc) return rc;
+  if (!out) return fail(DRRT_ERR_ARG, "null output pointer");
+  out[0] = V.q_min; out[1] = V.q_step; out[2] = kQ16VelStep;
+  return DRRT_OK;
+}
+
+extern "C" int drrt_q16_encode(const int res[3], float h, size_t n, const float* pos, const float* vel, void* pos_q,
+                               void* vel_q, void* stream) {
+  g_err[0] = 0;
+  Vol V; int rc = q16_vol(res, h, &V); if (rc) return rc;
+  if ((pos && !pos_q) || (vel && !vel_q)) return fail(DRRT_ERR_ARG, "null output pointer");
+  if (n == 0 || (!pos && !vel)) return DRRT_OK;
+  hipLaunchKernelGGL(k_q16_encode, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, 3 * n, pos, vel,
+                     (uint16_t*)pos_q, (int16_t*)vel_q);
+  LAUNCH_CHECK("k_q16_encode");
+  return DRRT_OK;
+}
+
+extern "C" int drrt_q16_decode(const int res[3], float h, size_t n, const void* pos_q, const void* vel_q, float* pos,
+                               float* vel, void* stream) {
+  g_err[0] = 0;
+  Vol V; int rc = q16_vol(res, h, &V); if (rc) return rc;
+  if ((pos_q && !pos) || (vel_q && !vel)) return fail(DRRT_ERR_ARG, "null output pointer");
+  if (n == 0 || (!pos_q && !vel_q)) return DRRT_OK;
+  hipLaunchKernelGGL(k_q16_decode, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, 3 * n,
+                     (const uint16_t*)pos_q, (const int16_t*)vel_q, pos, vel);
+  LAUNCH_CHECK("k_q16_decode");
+  return DRRT_OK;
+}
+
 extern "C" int drrt_trace_pln_f32(const float* rif, long long nvox, const int res[3], size_t n,
                                   const float* pos, const float* vel, const float* pln_o, const float* pln_d,
                                   float h, float ds, float* xt, float* vt, uint8_t* failmask,
@@ -1620,6 +1715,14 @@ extern "C" int drrt_backtrace_f16io(const float* rif, long long nvox, const int 
                                     float h, float ds, float* grad, drrt_stats* stats, void* ws,
                                     size_t ws_bytes, unsigned flags, void* stream) {
   return run_backtrace<0>(rif, nullptr, nvox, res, n, xt, vt, dx, dv, h, ds, grad, stats, ws, ws_bytes, flags, stream, 1);
+}
+
+extern "C" int drrt_backtrace_q16io(const float* rif, long long nvox, const int res[3], size_t n,
+                                    const void* xt, const void* vt, const void* dx, const void* dv,
+                                    float h, float ds, float* grad, drrt_stats* stats, void* ws,
+                                    size_t ws_bytes, unsigned flags, void* stream) {
+  return run_backtrace<0>(rif, nullptr, nvox, res, n, xt, vt, dx, dv, h, ds, grad, stats, ws, ws_bytes, flags, stream,
+                          (flags & DRRT_FLAG_Q16_POS_ONLY) ? 3 : 2);
 }
 
 extern "C" int drrt_backtrace_sdf_f32(const float* rif, const float* sdf, long long nvox, const int res[3],

@@ -30,8 +30,11 @@ namespace drrt {
 constexpr int kKeyBitsPerAxis = 10;
 constexpr int kKeyBits = 6 * kKeyBitsPerAxis;
 
-__device__ __forceinline__ float ldr(const void* p, size_t k, int half) {
-  return half ? __half2float(((const __half*)p)[k]) : ((const float*)p)[k];
+// one ray component in storage format `io` (0 fp32, 1 IEEE half, 2 the 16-bit ray state of drrt_device.h)
+__device__ __forceinline__ float ldr(const Vol& V, const void* p, size_t k, int io, bool is_pos) {
+  if (io == 3) return is_pos ? q16_pos_dec(V, ((const uint16_t*)p)[k]) : ((const float*)p)[k];
+  if (io == 2) return is_pos ? q16_pos_dec(V, ((const uint16_t*)p)[k]) : q16_vel_dec(((const int16_t*)p)[k]);
+  return io ? __half2float(((const __half*)p)[k]) : ((const float*)p)[k];
 }
 
 __global__ void __launch_bounds__(256) k_chord_keys(Vol V, size_t n, const void* __restrict__ pos,
@@ -39,9 +42,9 @@ __global__ void __launch_bounds__(256) k_chord_keys(Vol V, size_t n, const void*
                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float p[3] = {ldr(pos, 3 * i, io_half), ldr(pos, 3 * i + 1, io_half), ldr(pos, 3 * i + 2, io_half)};
-  float d[3] = {dir_sign * ldr(vel, 3 * i, io_half), dir_sign * ldr(vel, 3 * i + 1, io_half),
-                dir_sign * ldr(vel, 3 * i + 2, io_half)};
+  float p[3] = {ldr(V, pos, 3 * i, io_half, true), ldr(V, pos, 3 * i + 1, io_half, true), ldr(V, pos, 3 * i + 2, io_half, true)};
+  float d[3] = {dir_sign * ldr(V, vel, 3 * i, io_half, false), dir_sign * ldr(V, vel, 3 * i + 1, io_half, false),
+                dir_sign * ldr(V, vel, 3 * i + 2, io_half, false)};
   const float b[3] = {V.bx, V.by, V.bz};
   float tmin = 0.f, tmax = 3.0e38f;
   bool hit = true;

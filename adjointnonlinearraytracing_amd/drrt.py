@@ -132,8 +132,45 @@ def _is_half(*ts: torch.Tensor) -> bool:
     return all(t.dtype == torch.float16 for t in ts)
 
 
-def _rays(t: torch.Tensor, device: torch.device, n: Optional[int] = None, half: bool = False) -> torch.Tensor:
-    t = t.detach().to(device=device, dtype=torch.float16).contiguous() if half else _f32(t, device)
+def _is_q16(*ts: torch.Tensor) -> bool:
+    """16-bit ray state "q16" (include/drrt_hip.h): every position / direction tensor of the call is int16 codes."""
+    return all(t.dtype == torch.int16 for t in ts)
+
+
+def encode_rays16(res: Sequence[int], h: float, pos: Optional[torch.Tensor] = None, vel: Optional[torch.Tensor] = None):
+    """fp32 (n,3) positions / directions -> q16 codes (int16 tensors; position codes are unsigned 16-bit values stored
+    in int16 storage).  Rounded on the device exactly as the kernels round their outputs (drrt_q16_encode)."""
+    ref = pos if pos is not None else vel
+    dev = _dev(ref)
+    with torch.cuda.device(dev):
+        p_ = None if pos is None else _rays(pos, dev)
+        v_ = None if vel is None else _rays(vel, dev)
+        n = (p_ if p_ is not None else v_).shape[0]
+        pq = None if p_ is None else torch.empty(n, 3, dtype=torch.int16, device=dev)
+        vq = None if v_ is None else torch.empty(n, 3, dtype=torch.int16, device=dev)
+        _lib.check(_lib.load().drrt_q16_encode(_res3(res), float(h), n, _p(p_), _p(v_), _p(pq), _p(vq), _stream(dev)))
+    return tuple(t for t in (pq, vq) if t is not None) if (pos is not None and vel is not None) else (pq if pq is not None else vq)
+
+
+def decode_rays16(res: Sequence[int], h: float, pos_q: Optional[torch.Tensor] = None, vel_q: Optional[torch.Tensor] = None):
+    """q16 codes -> fp32 (exact widening, drrt_q16_decode)."""
+    ref = pos_q if pos_q is not None else vel_q
+    dev = _dev(ref)
+    with torch.cuda.device(dev):
+        n = ref.shape[0]
+        pq = None if pos_q is None else pos_q.detach().contiguous()
+        vq = None if vel_q is None else vel_q.detach().contiguous()
+        p_ = None if pq is None else torch.empty(n, 3, dtype=torch.float32, device=dev)
+        v_ = None if vq is None else torch.empty(n, 3, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().drrt_q16_decode(_res3(res), float(h), n, _p(pq), _p(vq), _p(p_), _p(v_), _stream(dev)))
+    return tuple(t for t in (p_, v_) if t is not None) if (pos_q is not None and vel_q is not None) else (p_ if p_ is not None else v_)
+
+
+def _rays(t: torch.Tensor, device: torch.device, n: Optional[int] = None, half: bool = False, q16: bool = False) -> torch.Tensor:
+    if q16:
+        t = t.detach().to(device=device).contiguous()
+    else:
+        t = t.detach().to(device=device, dtype=torch.float16).contiguous() if half else _f32(t, device)
     if t.dim() != 2 or t.shape[1] != 3 or (n is not None and t.shape[0] != n):
         raise RuntimeError(f"expected a ({'N' if n is None else n},3) ray tensor, got {tuple(t.shape)}")
     return t
@@ -245,18 +282,21 @@ class TracerC:
 
     # ---- forward ------------------------------------------------------------------------
     def trace(self, rif, res, pos, vel, h, ds) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Tracer::trace, src/tracer.cpp:35-100.  float16 pos AND vel select the fp16 ray-state
-        variant (drrt_trace_f16io): half in, fp32 march, half out."""
+        """Tracer::trace, src/tracer.cpp:35-100.  float16 pos AND vel select the IEEE-half ray-state variant
+        (drrt_trace_f16io: half in, fp32 march, half out); int16 pos AND vel (codes from ``encode_rays16``) select the
+        16-bit ray state "q16" (drrt_trace_q16io), which keeps sub-voxel positions -- see include/drrt_hip.h."""
         dev = _dev(rif)
         with torch.cuda.device(dev):
-            half = _is_half(pos, vel)
-            rif_, pos_ = _f32(rif, dev).reshape(-1), _rays(pos, dev, half=half)
+            half, q16 = _is_half(pos, vel), _is_q16(pos, vel)
+            qpos = (not q16) and pos.dtype == torch.int16          # q16 positions with fp32 directions
+            rif_, pos_ = _f32(rif, dev).reshape(-1), _rays(pos, dev, half=half, q16=q16 or qpos)
             n = pos_.shape[0]
-            vel_ = _rays(vel, dev, n, half=half)
+            vel_ = _rays(vel, dev, n, half=half, q16=q16)
             xt, vt = torch.empty_like(pos_), torch.empty_like(vel_)
-            fl = _flags()
+            fl = _flags() | (_lib.FLAG_Q16_POS_ONLY if qpos else 0)
+            q16 = q16 or qpos
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev), _new_stats(dev)
-            fn = _lib.load().drrt_trace_f16io if half else _lib.load().drrt_trace_f32
+            fn = _lib.load().drrt_trace_q16io if q16 else (_lib.load().drrt_trace_f16io if half else _lib.load().drrt_trace_f32)
             _lib.check(fn(
                 _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), float(h), float(ds),
                 _p(xt), _p(vt), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
@@ -345,13 +385,19 @@ class TracerC:
         dev = _dev(rif)
         with torch.cuda.device(dev):
             half = _is_half(xt, vt, dx, dv)
-            rif_, xt_ = _f32(rif, dev).reshape(-1), _rays(xt, dev, half=half)
+            q16 = _is_q16(xt, vt)                      # q16 exit rays + IEEE-half seeds (drrt_backtrace_q16io)
+            qpos = (not q16) and xt.dtype == torch.int16           # q16 positions; directions and seeds fp32
+            if q16 and not _is_half(dx, dv):
+                raise RuntimeError("q16 exit rays (int16) go with float16 seeds dx, dv")
+            rif_, xt_ = _f32(rif, dev).reshape(-1), _rays(xt, dev, half=half, q16=q16 or qpos)
             n = xt_.shape[0]
-            vt_, dx_, dv_ = _rays(vt, dev, n, half=half), _rays(dx, dev, n, half=half), _rays(dv, dev, n, half=half)
+            vt_ = _rays(vt, dev, n, half=half, q16=q16)
+            dx_, dv_ = _rays(dx, dev, n, half=half or q16), _rays(dv, dev, n, half=half or q16)
             grad = torch.empty_like(rif_)
-            fl = _flags(adjoint=True)
+            fl = _flags(adjoint=True) | (_lib.FLAG_Q16_POS_ONLY if qpos else 0)
+            q16 = q16 or qpos
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None), _new_stats(dev)
-            fn = _lib.load().drrt_backtrace_f16io if half else _lib.load().drrt_backtrace_f32
+            fn = _lib.load().drrt_backtrace_q16io if q16 else (_lib.load().drrt_backtrace_f16io if half else _lib.load().drrt_backtrace_f32)
             try:
                 _hint(order, n)
                 _lib.check(fn(

@@ -79,6 +79,8 @@ extern "C" {
                                           /*   default (0): skip the gather while the ray stays in the same cell            */
 #define DRRT_FLAG_NO_PIPELINE 0x40000u    /* backtrace / backtrace_sdf (A-B measurement; same results): the window kernel's
                                              loop without software pipelining (sample, bookkeeping, then step) */
+#define DRRT_FLAG_Q16_POS_ONLY 0x200000u  /* drrt_trace_q16io / drrt_backtrace_q16io: only the POSITION arrays are q16 codes;
+                                             directions and adjoint seeds are fp32 arrays (18 B per exit ray instead of 12) */
 #define DRRT_FLAG_LEGACY_FORWARD 0x100000u /* trace (A-B measurement; bit-identical results): k_trace<0> instead of k_trace_flat */
 #define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace (A-B measurement; same results up to fp32 summation order): the round-1
                                              window kernel k_backtrace_win instead of the reorganised k_backtrace_flat */
@@ -140,6 +142,41 @@ DRRT_API void drrt_set_order_hint(const uint32_t* order, size_t n);
 /* Length of the hint currently armed on this host thread (0 = none): lets a binding assert that no hint
  * survives a call. */
 DRRT_API size_t drrt_order_hint_pending(void);
+
+/* ---- 16-bit ray state "q16" (BASELINE.json config 5: "fp16 ray state + fp32 adjoint accumulate") -----------------
+ * The reference is fp32-only (include/types.h:36-46).  IEEE half keeps 11 significant bits wherever the value is:
+ * a position near 1.0 is rounded to 2^-11 = 1/8 voxel of a 256^3 grid, which changes the adjoint trajectories
+ * enough to move the gradient by 26 % rel-L2 (tests/test_baseline_configs.py, round 1).  The q16 formats spend the
+ * same 6 bytes per 3-vector where a march needs them:
+ *   positions   unsigned 16-bit codes c: p = q_min + c * q_step, over [-E/16, E + E/16] with E = max((res-1)*h);
+ *               q_step = 1.125 E / 65535 (= h/228 at 256^3); positions outside the range SATURATE
+ *   directions  signed 16-bit fixed point c: v = c * 2^-14 (range [-2, 2): |v| = n < 2); saturating
+ *   seeds       dx, dv of the adjoint: IEEE half (relative precision is what a seed needs; scale them into range)
+ * drrt_trace_q16io / drrt_backtrace_q16io widen exactly on load, march / accumulate in fp32 and round outputs once:
+ *   drrt_trace_q16io(encode(x), encode(v)) == encode(drrt_trace_f32(decode(encode(x)), decode(encode(v)))) bit for bit.
+ * drrt_q16_encode / drrt_q16_decode are the device-side conversions (either array may be NULL);
+ * drrt_q16_params returns {q_min, q_step, 2^-14} for a grid (host pointers).
+ * Tolerance (stated, no reference counterpart; tests/test_baseline_configs.py, 256^3 / 512 steps / 512^2 sensor / 262k
+ * rays): the gradient splat of a sample jumps by one voxel when the sample changes cell, and a perturbation of d voxels
+ * of the exit state makes a fraction ~d of the samples do so, so two SPARSE gradient grids (a handful of samples per
+ * voxel) differ by ~sqrt(d) rel-L2 whatever the storage format: IEEE half (d ~ 1/8) 0.26, q16 (d ~ 2e-3) 0.055 raw and
+ * 0.013 after a 3^3 box filter (the scale an optimiser sees); q16 positions with fp32 directions
+ * (DRRT_FLAG_Q16_POS_ONLY) 0.050 / 0.012.  Tested bounds: 0.1 raw, 2e-2 filtered.                                      */
+DRRT_API int drrt_q16_params(const int res[3], float h, float out[3]);
+DRRT_API int drrt_q16_encode(const int res[3], float h, size_t n, const float* pos, const float* vel,
+                    void* pos_q, void* vel_q, void* stream);
+DRRT_API int drrt_q16_decode(const int res[3], float h, size_t n, const void* pos_q, const void* vel_q,
+                    float* pos, float* vel, void* stream);
+DRRT_API int drrt_trace_q16io(const float* rif, long long nvox, const int res[3], size_t n,
+                     const void* pos_q, const void* vel_q, float h, float ds,
+                     void* xt_q, void* vt_q,
+                     drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                     unsigned flags, void* stream);
+DRRT_API int drrt_backtrace_q16io(const float* rif, long long nvox, const int res[3], size_t n,
+                         const void* xt_q, const void* vt_q, const void* dx_h, const void* dv_h,
+                         float h, float ds, float* grad,
+                         drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                         unsigned flags, void* stream);
 
 /* ---- forward marches ------------------------------------------------------------------- */
 

@@ -138,3 +138,15 @@ def test_order_hint_never_outlives_one_call(lib):
     h.drrt_set_order_hint(fake, n)
     h.drrt_set_order_hint(None, n)              # a null order disarms whatever n says
     assert h.drrt_order_hint_pending() == 0
+
+
+def test_q16_params_host_side(lib):
+    """drrt_q16_params is host-only: q_min = -E/16, q_step = 1.125 E / 65535 with E the largest box extent, 2^-14."""
+    import ctypes as C
+    h = lib.load()
+    out = (C.c_float * 3)()
+    assert h.drrt_q16_params((C.c_int * 3)(256, 256, 256), C.c_float(1.0 / 255), out) == 0
+    E = 255 * float(C.c_float(1.0 / 255).value)
+    assert abs(out[0] + E / 16) < 1e-6 and abs(out[1] - 1.125 * E / 65535) < 1e-9 and out[2] == 2.0 ** -14
+    assert h.drrt_q16_params((C.c_int * 3)(4, 9, 5), C.c_float(0.5), out) == 0 and abs(out[0] + 4.0 / 16) < 1e-7
+    assert h.drrt_q16_params((C.c_int * 3)(4, 0, 5), C.c_float(0.5), out) < 0

@@ -190,6 +190,82 @@ def test_config4_image_caustic_fp16_rays_512_sensor(gpu, D):
     assert float((a @ b) / (a.norm() * b.norm())) >= 0.9
 
 
+def test_config4_q16_ray_state_keeps_the_gradient(gpu, D):
+    """configs[4] with the 16-bit ray state "q16" (include/drrt_hip.h): the same 6 bytes per
+    3-vector as IEEE half, but positions as box-relative 16-bit codes (h/228 at 256^3) and directions as 2^-14 fixed
+    point.  trace(q16) -> sensor image -> MSE -> backward through the sensor -> backtrace(q16 exit rays, half seeds)
+    against the fp32 pipeline on the SAME (decoded) input rays.  No reference counterpart (include/types.h:36-46 is
+    fp32-only).  Stated tolerances: raw grids <= 0.1 rel-L2 (measured 0.055; IEEE half 0.26), 3^3-box-filtered grids
+    <= 2e-2 (measured 0.013) -- see the comment at the comparison for why the raw figure is ~sqrt(perturbation)."""
+    from adjointnonlinearraytracing_amd import sensor
+    import bench
+    rif, pos, vel, h, ds = bench.make_workload(256, 512 * 512, gpu, seed=5)
+    span = 1.0
+    # A view in GENERAL position, as the rotated views of the image experiments are (core/image_opt.py:60-66,
+    # source.random_rotate_ic): the bench workload starts exactly on the y = 0 face with v = +y and ds = h/2, so every
+    # second sample lies EXACTLY on a cell face and any perturbation flips half of them -- a degenerate worst case
+    # for the discontinuous gradient splat (measured there: q16 0.07, IEEE half 0.26).
+    pos = pos.clone(); pos[:, 1] = -0.3 * ds
+    vel = torch.tensor([[0.031, 1.0, -0.017]], device=gpu).expand_as(pos).contiguous()
+    vel = vel / vel.norm(dim=1, keepdim=True)
+    p = torch.tensor([[0.5, 1.0 + 2 * h, 0.5]], device=gpu); nn = torch.tensor([[0.0, 1.0, 0.0]], device=gpu)
+    tt = torch.tensor([[0.0, 0.0, 1.0]], device=gpu)
+    target = torch.zeros(512, 512, device=gpu); target[192:320, 192:320] = 1.0
+    T = D.TracerC()
+    res = rif.shape
+    xq, vq = D.encode_rays16(res, h, pos, vel)
+    assert xq.dtype == torch.int16 and xq.shape == pos.shape
+    x0, v0 = D.decode_rays16(res, h, xq, vq)                              # what the q16 inputs mean exactly
+    # half a code, plus the fp32 rounding of the decode itself
+    assert float((x0 - pos).abs().max()) <= 0.5 * 1.125 / 65535 + 2e-7 and float((v0 - vel).abs().max()) <= 0.5 / 16384 + 2e-7
+    grads = {}
+    for mode in ("q16", "qpos", "f32"):
+        if mode == "q16":
+            xt, vt = T.trace(rif, res, xq, vq, h, ds)
+            assert xt.dtype == torch.int16
+            order = D.last_order
+            xs, vs = D.decode_rays16(res, h, xt, vt)
+        elif mode == "qpos":                                           # q16 positions, fp32 directions
+            xt, vt = T.trace(rif, res, xq, v0, h, ds)
+            assert xt.dtype == torch.int16 and vt.dtype == torch.float32
+            order = D.last_order
+            xs, vs = D.decode_rays16(res, h, pos_q=xt), vt
+        else:
+            xt, vt = T.trace(rif, res, x0, v0, h, ds)
+            order = D.last_order
+            xs, vs = xt, vt
+        xs, vs = xs.clone().requires_grad_(True), vs.clone().requires_grad_(True)
+        img = sensor.generate_sensor((xs, vs), 1.0, (p, nn), 512, span, tt)
+        img = img * (img.numel() / img.sum().detach())                   # source.sum_norm (core/source.py:415-420)
+        loss = torch.nn.functional.mse_loss(img, target * (target.numel() / target.sum()))
+        loss.backward()
+        gx, gv = xs.grad, vs.grad
+        if mode == "q16":
+            scale = 1.0 / float(torch.maximum(gx.abs().max(), gv.abs().max()))      # keep the seeds inside fp16 range
+            g = T.backtrace(rif, res, xt, vt, (gx * scale).half(), (gv * scale).half(), h, ds, order=order) / scale
+        else:                                                          # "qpos": int16 xt with fp32 vt and seeds
+            g = T.backtrace(rif, res, xt, vt, gx, gv, h, ds, order=order)
+        assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+        grads[mode] = (g, float(loss.detach()), xs.detach())
+    # exit rays: the q16 outputs are the fp32 outputs rounded once (bit-identity is tested in test_gpu_parity)
+    assert float((grads["q16"][2] - grads["f32"][2]).abs().max()) <= 0.5 * 1.125 / 65535 + 2e-7
+    assert abs(grads["q16"][1] - grads["f32"][1]) <= 2e-3 * abs(grads["f32"][1])
+    b = grads["f32"][0].double().flatten()
+    rel = {m: float((grads[m][0].double().flatten() - b).norm() / b.norm()) for m in ("q16", "qpos")}
+    # The raw grids compare two SPARSE samplings (262k rays into 16.7M voxels: a handful of samples per voxel).  A sample
+    # whose cell changes under a d-voxel perturbation moves its +-g pattern by one voxel; a fraction ~d of the samples
+    # does, so the raw rel-L2 is ~sqrt(d) whatever the format (measured: 0.05 at d = 2e-3).  What an optimiser sees is
+    # the field at the scale of a few voxels: the same comparison after a 3^3 box filter.
+    def smooth(g):
+        return torch.nn.functional.avg_pool3d(g.reshape(1, 1, *res).double(), 3, stride=1, padding=1).flatten()
+    bs = smooth(grads["f32"][0])
+    rel_s = {m: float((smooth(grads[m][0]) - bs).norm() / bs.norm()) for m in ("q16", "qpos")}
+    print(f"gradient rel-L2 vs fp32 ray state: q16 raw {rel['q16']:.3e} / 3^3-filtered {rel_s['q16']:.3e}; "
+          f"q16 positions + fp32 directions raw {rel['qpos']:.3e} / filtered {rel_s['qpos']:.3e}")
+    assert rel["q16"] <= 0.1 and rel["qpos"] <= 0.1          # raw: ~sqrt(perturbation in voxels); measured 0.055 / 0.050 (IEEE half: 0.26)
+    assert rel_s["q16"] <= 2e-2 and rel_s["qpos"] <= 2e-2    # at the scale of a few voxels; measured 0.0131 / 0.0123
+
+
 def test_large_noncubic_grid_512x384x320(gpu, oracle, D):
     """Beyond BASELINE's sizes: a 63M-voxel NON-cubic grid (flat offsets above 2^24, res = (W,H,D) all
     different) with oblique rays -- forward bit-exact and adjoint within summation-order tolerance against

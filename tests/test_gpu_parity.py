@@ -745,3 +745,39 @@ def test_adjoint_kernel_variants_agree(gpu, oracle, drrt_mod, kind, R, step_res)
     base = grads[("flat", 1)]
     for k, g in grads.items():
         assert cases.rel_l2(g, base) <= 2e-5, k
+
+
+def test_q16_ray_state_mode(gpu, drrt_mod):
+    """16-bit ray state "q16" (include/drrt_hip.h): trace_q16io / backtrace_q16io widen exactly, march in fp32 and round
+    once -- trace_q16io(enc(x), enc(v)) == enc(trace_f32(dec(enc(x)), dec(enc(v)))) bit for bit, and the adjoint from
+    q16 exit rays + half seeds equals the fp32 adjoint fed the decoded / widened arrays (same arithmetic, fp32 sums)."""
+    R, span, n = 65, 1.0, 30000
+    h = span / (R - 1); ds = h / 2
+    rif = _t(cases.luneburg(R), gpu)
+    pos, vel = cases.cube_rays(n // 6, span, ds, seed=8, tilt=0.2)
+    pos, vel = _t(pos, gpu), _t(vel, gpu)
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = True
+    xq, vq = drrt_mod.encode_rays16(rif.shape, h, pos, vel)
+    x0, v0 = drrt_mod.decode_rays16(rif.shape, h, xq, vq)
+    # codes round-trip exactly; decode(encode(.)) is within half a code of the input; saturation at the range ends
+    xq2, vq2 = drrt_mod.encode_rays16(rif.shape, h, x0, v0)
+    assert torch.equal(xq2, xq) and torch.equal(vq2, vq)
+    far = torch.tensor([[-50.0, 0.5, 50.0]], device=gpu); big = torch.tensor([[3.0, -3.0, float("nan")]], device=gpu)
+    fq, bq = drrt_mod.encode_rays16(rif.shape, h, far, big)
+    assert fq.view(torch.uint16).tolist()[0][0] == 0 and fq.view(torch.uint16).tolist()[0][2] == 65535
+    assert bq.tolist()[0] == [32767, -32768, -32768]
+    xt_q, vt_q = T.trace(rif, rif.shape, xq, vq, h, ds)
+    st_q = drrt_mod.read_stats()
+    order = drrt_mod.last_order
+    xt_f, vt_f = T.trace(rif, rif.shape, x0, v0, h, ds)
+    assert drrt_mod.read_stats() == st_q
+    ex, ev = drrt_mod.encode_rays16(rif.shape, h, xt_f, vt_f)
+    assert torch.equal(xt_q, ex) and torch.equal(vt_q, ev)
+    dx = torch.randn(xt_q.shape, device=gpu).half(); dv = torch.randn(xt_q.shape, device=gpu).half()
+    g_q = T.backtrace(rif, rif.shape, xt_q, vt_q, dx, dv, h, ds, order=order)
+    xd, vd = drrt_mod.decode_rays16(rif.shape, h, xt_q, vt_q)
+    g_f = T.backtrace(rif, rif.shape, xd, vd, dx.float(), dv.float(), h, ds, order=order)
+    assert cases.rel_l2(g_q.cpu().numpy(), g_f.cpu().numpy()) <= 2e-5
+    with pytest.raises(RuntimeError, match="float16 seeds"):
+        T.backtrace(rif, rif.shape, xt_q, vt_q, dx.float(), dv.float(), h, ds)
