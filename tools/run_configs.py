@@ -115,5 +115,25 @@ t = timed(lambda: T.trace(rif, rif.shape, p16, v16, h, dsv))
 xt, vt = T.trace(rif, rif.shape, pos, vel, h, dsv)
 p = torch.tensor([[0.5, 1.01, 0.5]], device=dev); nn = torch.tensor([[0.0, 1.0, 0.0]], device=dev); tt = torch.tensor([[0.0, 0.0, 1.0]], device=dev)
 ts = timed(lambda: sensor.generate_sensor((xt, vt), 1.0, (p, nn), 512, 1.0, tt))
-out["config4_fp16_trace_and_sensor"] = dict(trace_f16io_ms=t * 1e3, sensor_splat_512_ms=ts * 1e3, rays=1024 * 1024)
+xq, vq = drrt.encode_rays16(rif.shape, h, pos, vel)
+tq = timed(lambda: T.trace(rif, rif.shape, xq, vq, h, dsv))
+tf = timed(lambda: sensor.generate_inf_sensor((xt, vt), 1, (p, nn), 512, 120, tt))
+out["config4_fp16_trace_and_sensor"] = dict(trace_f16io_ms=t * 1e3, trace_q16io_ms=tq * 1e3, sensor_splat_512_ms=ts * 1e3,
+                                            far_sensor_splat_512_ms=tf * 1e3, rays=1024 * 1024)
+
+# autograd wrappers (core/tracer.py counterpart): forward + backward through BackTracerC, python overhead included
+from adjointnonlinearraytracing_amd import tracer, source
+rif_p = rif.clone().requires_grad_(True)
+
+
+def fb():
+    a, b = tracer.BackTracerC.apply(rif_p, pos, vel, h, dsv)
+    (a.sum() + b.sum()).backward()
+    rif_p.grad = None
+
+
+tfb = timed(fb)
+out["autograd_BackTracerC_256cube_1M"] = dict(fwd_plus_bwd_ms=tfb * 1e3, note="trace + backtrace + torch autograd glue, one sync")
+tc = timed(lambda: source.cone_source3_rand(torch.tensor(0.0), (512, 512), 4, 2.0, cone_angle=40.0, device=dev))
+out["cone_source_1M_rays_ms"] = tc * 1e3
 print(json.dumps(out, indent=1))
