@@ -195,12 +195,14 @@ def load_pmc():
     return None, None
 
 
-def pmc_kernel(pmc, prefix):
+def pmc_kernel(pmc, *prefixes):
+    """First kernel of the PMC summary whose name starts with one of `prefixes` (in order of preference)."""
     if not pmc:
         return None
-    for k, v in pmc.items():
-        if k.startswith(prefix):
-            return v
+    for prefix in prefixes:
+        for k, v in pmc.items():
+            if k.startswith(prefix):
+                return v
     return None
 
 
@@ -212,7 +214,7 @@ def physical_bound(pk, ms, lane_addresses):
         return out
     cyc = ms * 1e-3 * CLK_HZ
     ta = lane_addresses / (TA_LANES_PER_CLK_CU * 256 * cyc)
-    out["ta_gather_frac"] = ta
+    out["ta_gather_frac_est"] = ta
     if pk and "SQ_INSTS_VALU" in pk:
         valu = pk["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMD * cyc)
         out["valu_issue_frac"] = valu
@@ -418,26 +420,30 @@ def run_rank(args) -> int:
                        and not args.experiment and not args.quad and not args.lds_bricks and not args.fwd_flags
                        and not args.adj_flags)
         pmc, pmc_src = load_pmc() if default_cfg else (None, None)
-        pk_adj, pk_fwd = pmc_kernel(pmc, "drrt::k_backtrace_win"), pmc_kernel(pmc, "drrt::k_trace<0>")
+        pk_adj = pmc_kernel(pmc, "drrt::k_backtrace_flat", "drrt::k_backtrace_win")
+        pk_fwd = pmc_kernel(pmc, "drrt::k_trace_flat", "drrt::k_trace<0>")
         tr_adj = pk_adj and pk_adj.get("hbm_traffic_bytes_per_launch")
         tr_fwd = pk_fwd and pk_fwd.get("hbm_traffic_bytes_per_launch")
         src_note = (f"{pmc_src}: rocprofv3 --pmc passes of this command, committed; read from that file, NOT "
                     f"measured in this run") if pmc_src else None
         shard = (f"the metric's single set of {args.rays} rays split into {world} contiguous shards "
                  f"({n} on rank 0)") if main_mode == "strong" else f"{n} rays per GPU (own seed per rank)"
-        roof = {"bound": "hbm", "kernel": "adjoint march (k_backtrace_win)", "achieved": ach_adj,
+        roof = {"bound": "hbm", "kernel": "adjoint march (k_backtrace_flat)", "achieved": ach_adj,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_adj / HBM_PEAK_GBS, "traffic": tr_adj,
                 "traffic_source": src_note, "pmc_source": pmc_src,
                 "hbm_measured_gbps": (tr_adj / (ms_adj * 1e-3) / 1e9) if tr_adj else None,
                 "algorithmic_bytes_per_ray_step": B_ADJ, "ray_steps_per_launch": adj_steps, "avg_kernel_ms": ms_adj}
-        roof.update(physical_bound(pk_adj, ms_adj, 4.0 * adj_steps))
-        roof_f = {"bound": "hbm", "kernel": "forward march (k_trace)", "achieved": ach_fwd,
+        # gather lane-addresses: 4 pair loads per lane-step in which the ray ENTERS a new cell; with ds = h/2 that is
+        # ~0.6 of the lane-steps (every second step along the main axis + the transverse crossings) -- an estimate
+        GATHER_FRACTION = 0.6
+        roof.update(physical_bound(pk_adj, ms_adj, 4.0 * GATHER_FRACTION * adj_steps))
+        roof_f = {"bound": "hbm", "kernel": "forward march (k_trace_flat)", "achieved": ach_fwd,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_fwd / HBM_PEAK_GBS, "traffic": tr_fwd,
                   "traffic_source": src_note, "pmc_source": pmc_src,
                   "hbm_measured_gbps": (tr_fwd / (ms_fwd * 1e-3) / 1e9) if tr_fwd else None,
                   "algorithmic_bytes_per_ray_step": B_FWD, "ray_steps_per_launch": fwd_steps, "avg_kernel_ms": ms_fwd,
                   "note": "frac can exceed 1: SURVEY 8.6 counts every tap as an HBM read, but the taps are cache-served"}
-        roof_f.update(physical_bound(pk_fwd, ms_fwd, 4.0 * fwd_steps))
+        roof_f.update(physical_bound(pk_fwd, ms_fwd, 4.0 * GATHER_FRACTION * fwd_steps))
         out = {
             "metric": "ray-steps/sec (fwd+adjoint), 256^3 RIF grid, 1M rays x 512 steps",
             "value": m["fwd_total"] * args.steps / m["elapsed"],
