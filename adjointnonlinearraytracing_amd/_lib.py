@@ -22,8 +22,9 @@ FLAG_NO_ZERO = 4
 FLAG_DIRECT_ATOMICS = 8
 FLAG_DEBUG_COUNTERS = 16
 FLAG_LDS_BRICKS = 32
-FLAG_QUAD_GRID = 64
-FLAG_QUAD_REUSE = 128
+FLAG_PAIR_GRID = 64
+FLAG_PAIR_REUSE = 128
+FLAG_QUAD_GRID, FLAG_QUAD_REUSE = FLAG_PAIR_GRID, FLAG_PAIR_REUSE      # round-1 names
 FLAG_TAP_REUSE_OFF, FLAG_TAP_REUSE_FACE = 0x10000, 0x20000
 FLAG_NO_PIPELINE = 0x40000
 FLAG_LEGACY_ADJOINT = 0x80000

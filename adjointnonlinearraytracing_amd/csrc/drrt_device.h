@@ -40,8 +40,8 @@ struct Vol {
   float inv_h2;         // inv_h*inv_h
   float bx, by, bz;     // (float)(res-1)*h : bounds of inbounds/escaped (src/volume.cpp:252-254)
   unsigned lx, ly, lz;  // res-3 (0 when res < 4): a floor index i with 1 <= i <= res-3 is "strictly interior"
-  const float4* quad;   // optional (device only): quad[i] = {n[i], n[i+1], n[i+sy], n[i+sy+1]} for every voxel i
-                        // (clamped at the far x / y faces), built per call by k_build_quad; null = not in use
+  const float* pair;    // optional (device only): the "pair copy" of the grid, 2 floats per voxel i: {n[i], n[i+sy]}
+                        // (clamped at the far y face), built per call by k_build_pair; null = not in use
   float q_min, q_step, q_inv_step;   // 16-bit ray-state positions ("q16", include/drrt_hip.h): p = q_min + code * q_step
 };
 
@@ -67,7 +67,7 @@ DRRT_HD int16_t q16_vel_enc(float v) {
 }
 
 DRRT_HD void vol_finish(Vol& V, float h) {   // derived fields; data, W, H, D must be set
-  V.sy = V.W; V.sz = V.W * V.H; V.quad = nullptr;
+  V.sy = V.W; V.sz = V.W * V.H; V.pair = nullptr;
   V.inv_h = 1.0f / h; V.inv_h2 = V.inv_h * V.inv_h;
   V.bx = (float)(V.W - 1) * h; V.by = (float)(V.H - 1) * h; V.bz = (float)(V.D - 1) * h;
   V.lx = V.W >= 4 ? (unsigned)(V.W - 3) : 0u; V.ly = V.H >= 4 ? (unsigned)(V.H - 3) : 0u;
@@ -173,20 +173,32 @@ DRRT_HD Taps fetch(const float* __restrict__ d, const Cell& c) {
   return t;
 }
 
-// The march's gather is bound by the texture addresser, whose cost is per lane-address and almost flat in
-// the access width up to 16 bytes (tools/gather_bench.hip: four 8-byte gathers 1.00 ms, two 16-byte gathers
-// 0.57 ms for the same 8 corners).  With the quad copy of the grid a strictly interior cell is two 16-byte
-// loads: the (x,y) quad at z0 and the one at z0+1.  Same floats, same Taps -> bit-identical results.
+// The march's gather is bound by the texture addresser, and its cost is per gather INSTRUCTION: ~30-37 cycles of the
+// CU's addresser for a divergent 64-lane load, the same with one active lane as with 64, and only ~15 % more for 16
+// bytes per lane than for 8 (tools/chain_bench.hip, tools/gather_bench.hip).  With the pair copy of the grid --
+// P[i] = {n[i], n[i+sy]}, the y-neighbour interleaved -- ONE 16-byte load at (x0, y0, z) returns the four taps of a
+// z-face, {n(x0,y0), n(x0,y1), n(x0+1,y0), n(x0+1,y1)}, so a strictly interior cell is two loads instead of four
+// (and the copy is 2x the grid, against 4x for a full (x,y) quad per voxel).  Same floats -> bit-identical results.
+typedef float f4 __attribute__((ext_vector_type(4)));
+DRRT_HD Taps taps_from_pair(f4 q0, f4 q1) {      // q0 = face z0, q1 = face z1 of the pair copy
+  Taps t;
+  t.a = f2{q0.x, q0.z}; t.b = f2{q0.y, q0.w};
+  t.e = f2{q1.x, q1.z}; t.f = f2{q1.y, q1.w};
+  return t;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ f4 ld_quad8(const float* p) {      // 16 bytes at 8-byte alignment: one global_load_dwordx4
+  typedef float __attribute__((ext_vector_type(4), aligned(8))) f4u;
+  const f4u a = *reinterpret_cast<const f4u*>(p);
+  return f4{a.x, a.y, a.z, a.w};
+}
+#endif
 DRRT_HD Taps fetch_vol(const Vol& V, const Cell& c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (V.quad != nullptr && c.interior) {
+  if (V.pair != nullptr && c.interior) {
     __builtin_assume(c.base >= 0 && c.base < (1 << 29));
-    const float4 a = V.quad[(unsigned)c.base];
-    const float4 b = V.quad[(unsigned)c.base + (unsigned)V.sz];
-    Taps t;
-    t.a = f2{a.x, a.y}; t.b = f2{a.z, a.w};
-    t.e = f2{b.x, b.y}; t.f = f2{b.z, b.w};
-    return t;
+    const float* p = V.pair + 2u * (unsigned)c.base;
+    return taps_from_pair(ld_quad8(p), ld_quad8(p + 2u * (unsigned)V.sz));
   }
 #endif
   return fetch(V.data, c);
@@ -206,7 +218,7 @@ struct TapCache { Taps t; int base; };     // base < 0: nothing cached
 
 template <int REUSE>
 DRRT_HD void fetch_reuse(const Vol& V, const Cell& c, TapCache& tc) {
-  if (REUSE == 0 || V.quad != nullptr) { tc.t = fetch_vol(V, c); return; }
+  if (REUSE == 0 || V.pair != nullptr) { tc.t = fetch_vol(V, c); return; }
   if (!c.interior) { tc.t = fetch(V.data, c); tc.base = -1; return; }
   if (c.base == tc.base) return;
   Taps& t = tc.t;

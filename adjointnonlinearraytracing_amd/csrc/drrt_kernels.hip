@@ -155,78 +155,166 @@ __global__ void __launch_bounds__(kBlock) k_trace(TraceArgs a) {
 // ---------------------------------------------------------------------------------------------
 // k_trace_flat: Tracer::trace (MODE 0) with the loop written out flat -- the same per-step arithmetic as trace_ray /
 // fwd_step_c (drrt_device.h), but the cell is located IN PLACE (nothing but position, fractions, flat index and the
-// 8 taps is carried from step to step), a strictly interior step touches no box test, no masked-zero taps and no
-// clamp offsets, and the gather of the next cell is skipped while the ray stays in its cell.  Boundary cells (the
+// 8 taps is carried from step to step), a strictly interior step touches no box test, no exit record and no clamp
+// offsets, and the gather of the next cell is skipped while the ray stays in its cell.  Boundary cells (the
 // outermost layer, where the clamps and the inbounds / escaped tests matter) take the generic path of drrt_device.h.
 // Bit-identical to k_trace<0> (tests/test_gpu_parity.py).
+//
+// What bounds it (tools/chain_bench.hip, PMC): a wave issues a gather on nearly every step -- some lane always changes
+// cell -- and a divergent 64-lane gather instruction occupies the CU's texture addresser for ~30-37 cycles whether one
+// lane is active or all 64.  So the taps a lane keeps across steps save cache traffic but hardly any addresser time;
+// what does is FEWER GATHER INSTRUCTIONS: with the pair copy of the grid (DRRT_FLAG_PAIR_GRID, template PAIR) a cell
+// is two 16-byte gathers instead of four 8-byte ones (1.31 -> 1.06 ms on 256^3 / 1M rays).  Tried and dropped: two rays
+// per lane (two gathers in flight per wave: 1.6-1.9 ms -- the addresser, not latency, is the limit), a branch-free
+// interior path (1.38 ms), fewer VALU instructions alone (-20 %: no change).
 // ---------------------------------------------------------------------------------------------
+// (int)floorf(f) in one instruction (v_cvt_flr_i32_f32: floor, then the saturating conversion of v_cvt_i32_f32)
+__device__ __forceinline__ int cvt_floor_i32(float f) {
+  int i;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(f));
+  return i;
+}
+
+// the four rows of a cell's taps as wave-uniform base pointers + ONE 32-bit byte offset per lane
+// (global_load ... saddr: one shift instead of four 64-bit address computations per gather)
+struct TapRows { const char *d00, *d10, *d01, *d11; };
+template <bool PAIR>
+__device__ __forceinline__ TapRows tap_rows(const Vol& V) {
+  TapRows R;
+  if (PAIR) {                                   // pair copy: the z0 and the z1 face, 8 bytes per voxel
+    R.d00 = (const char*)V.pair;
+    R.d01 = R.d00 + 8u * (unsigned)V.sz;
+    R.d10 = R.d11 = nullptr;
+  } else {
+    R.d00 = (const char*)V.data;
+    R.d10 = R.d00 + 4u * (unsigned)V.sy;
+    R.d01 = R.d00 + 4u * (unsigned)V.sz;
+    R.d11 = R.d01 + 4u * (unsigned)V.sy;
+  }
+  return R;
+}
+// The 8 taps of a cell as the two 16-byte halves they are gathered as.  off = byte offset of corner 000 in the array
+// gathered from (4 * flat index on the plain grid, 8 * flat index on the pair copy).
+//   plain grid: q0 = (v000, v100 | v010, v110), q1 = (v001, v101 | v011, v111)   -- four 8-byte loads
+//   pair copy : q0 = (v000, v010, v100, v110),  q1 = (v001, v011, v101, v111)    -- two 16-byte loads
+template <bool PAIR>
+__device__ __forceinline__ void gather_rows(const TapRows& R, unsigned off, f4& q0, f4& q1) {
+  if (PAIR) {
+    q0 = ld_quad8((const float*)(R.d00 + off)); q1 = ld_quad8((const float*)(R.d01 + off));
+  } else {
+    const f2 a = ld_pair((const float*)(R.d00 + off)), b = ld_pair((const float*)(R.d10 + off));
+    const f2 e = ld_pair((const float*)(R.d01 + off)), f = ld_pair((const float*)(R.d11 + off));
+    q0 = f4{a.x, a.y, b.x, b.y}; q1 = f4{e.x, e.y, f.x, f.y};
+  }
+}
+template <bool PAIR>
+__device__ __forceinline__ Taps taps_of(f4 q0, f4 q1) {
+  if (PAIR) return taps_from_pair(q0, q1);
+  Taps t;
+  t.a = f2{q0.x, q0.y}; t.b = f2{q0.z, q0.w}; t.e = f2{q1.x, q1.y}; t.f = f2{q1.z, q1.w};
+  return t;
+}
+template <bool PAIR>
+__device__ __forceinline__ void taps_set(const Taps& t, f4& q0, f4& q1) {
+  if (PAIR) { q0 = f4{t.a.x, t.b.x, t.a.y, t.b.y}; q1 = f4{t.e.x, t.f.x, t.e.y, t.f.y}; }
+  else      { q0 = f4{t.a.x, t.a.y, t.b.x, t.b.y}; q1 = f4{t.e.x, t.e.y, t.f.x, t.f.y}; }
+}
+template <bool PAIR> __device__ __forceinline__ unsigned tap_offset(int base) { return (unsigned)base << (PAIR ? 3 : 2); }
+
+// One marching ray of k_trace_flat.  No exit-record registers: the march of a ray ends at the step that sets
+// `escaped` (:75-76, per-ray form of :82), so the record (:79-80) is the final state when the ray CROSSED out of
+// the box at that step, and the initial state (:56-57, re-read from the input) otherwise.
+struct FlatRay {
+  float x, y, z, vx, vy, vz, wx, wy, wz;
+  unsigned off;            // BYTE offset (tap_offset) of the cell whose taps the lane holds, i.e. the load offset itself
+  f4 q0, q1;               // the taps (gather_rows)
+  unsigned steps;
+  bool inside, interior, live, crossed;
+};
+
+template <bool PAIR>
+__device__ __forceinline__ void flat_begin(const Vol& V, const TapRows& R, FlatRay& r, const Ray3& p, const Ray3& u) {
+  r.x = p.x; r.y = p.y; r.z = p.z; r.vx = u.x; r.vy = u.y; r.vz = u.z;
+  r.inside = inbounds(V, r.x, r.y, r.z);                                                    // :61
+  r.live = true; r.crossed = false; r.steps = 0;                                            // :62
+  const Cell c = locate(V, r.x, r.y, r.z);
+  r.off = tap_offset<PAIR>(c.base); r.wx = c.wx; r.wy = c.wy; r.wz = c.wz; r.interior = c.interior;
+  r.q0 = r.q1 = f4{0.f, 0.f, 0.f, 0.f};
+  if (r.interior) gather_rows<PAIR>(R, r.off, r.q0, r.q1);
+}
+
+// The box tests of a ray that has just stepped into a boundary cell (:73-76, :86): may end the ray.
+__device__ __forceinline__ void flat_boundary(const Vol& V, int it, FlatRay& r) {
+  const bool cur_inside = inbounds(V, r.x, r.y, r.z);                                       // :73
+  const bool esc_now = escaped(V, r.x, r.y, r.z, r.vx, r.vy, r.vz);                         // :76
+  const bool cross = r.inside & !cur_inside;                                                // :74
+  r.inside = cur_inside;                                                                    // :86
+  if (cross | esc_now) { r.crossed = cross; r.live = false; r.steps = (unsigned)it + 1u; }  // :75-76
+}
+
+// One iteration of one ray (any state), up to the point where the cell of the new position is known.  Returns true
+// when the taps of that cell have to be gathered (the caller issues the gather).
+// In-place locate(): the floor index by one conversion; the fractions by v_fract, == f - floor(f) bit for bit for the
+// non-negative coordinates of an interior cell.  The fractions (and clamp offsets) of a BOUNDARY cell are not
+// carried: they are re-derived by locate() when such a cell is sampled.
+template <bool PAIR>
+__device__ __forceinline__ bool flat_advance(const Vol& V, float ds, int it, FlatRay& r) {
+  if (r.inside) {                                                                           // masked gather (Q4)
+    if (!r.interior) {                            // boundary cell: clamp offsets and fractions from the position, taps fetched here
+      const Cell cb = locate(V, r.x, r.y, r.z);
+      taps_set<PAIR>(fetch(V.data, cb), r.q0, r.q1);
+      r.wx = cb.wx; r.wy = cb.wy; r.wz = cb.wz;
+    }
+    const Sample q = interp<false>(taps_of<PAIR>(r.q0, r.q1), r.wx, r.wy, r.wz);
+    const float gx = q.gx * V.inv_h, gy = q.gy * V.inv_h, gz = q.gz * V.inv_h;
+    const float dsn = ds * q.n;
+    r.vx = fmaf(dsn, gx, r.vx); r.vy = fmaf(dsn, gy, r.vy); r.vz = fmaf(dsn, gz, r.vz);     // :70
+  }
+  r.x = fmaf(ds, r.vx, r.x); r.y = fmaf(ds, r.vy, r.y); r.z = fmaf(ds, r.vz, r.z);          // :71
+  const float fx = r.x * V.inv_h, fy = r.y * V.inv_h, fz = r.z * V.inv_h;
+  const int ix = cvt_floor_i32(fx), iy = cvt_floor_i32(fy), iz = cvt_floor_i32(fz);
+  const bool was_interior = r.interior;
+  r.interior = (((unsigned)ix - 1u) < V.lx) & (((unsigned)iy - 1u) < V.ly) & (((unsigned)iz - 1u) < V.lz);
+  if (r.interior) {
+    // strictly interior: in bounds, not escaped, nothing to record (Cell::interior) -- sample weights and taps only
+    r.wx = __builtin_amdgcn_fractf(fx); r.wy = __builtin_amdgcn_fractf(fy); r.wz = __builtin_amdgcn_fractf(fz);
+    const unsigned noff = tap_offset<PAIR>(mad24(iz, V.sz, mad24(iy, V.sy, ix)));
+    r.inside = true;                                                                        // :73, :86
+    if (!(was_interior & (noff == r.off))) { r.off = noff; return true; }
+  } else {
+    flat_boundary(V, it, r);
+  }
+  return false;
+}
+
+template <bool PAIR>   // PAIR: gather from the pair copy of the grid (two 16-byte loads per cell, see gather_rows)
 __global__ void __launch_bounds__(kBlock) k_trace_flat(TraceArgs a) {
   const Vol& V = a.vol;
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const TapRows R = tap_rows<PAIR>(V);
   unsigned steps = 0, failed = 0;
   size_t i;
   if (ray_index(a.perm, t, a.n, i)) {
-    const Ray3 p = ld3(a.pos, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vel, i, a.io_half, &a.vol, RAY_VEL);
-    float x = p.x, y = p.y, z = p.z, vx = u.x, vy = u.y, vz = u.z;
-    float xtx = x, xty = y, xtz = z, vtx = vx, vty = vy, vtz = vz;                       // :56-57
-    bool inside = inbounds(V, x, y, z), esc = false;                                        // :61-62
-    Cell c = locate(V, x, y, z);
-    int base = c.base;
-    float wx = c.wx, wy = c.wy, wz = c.wz;
-    bool interior = c.interior;
-    Taps tp = taps_zero();
-    // the four rows of a cell's taps as wave-uniform base pointers + ONE 32-bit byte offset per lane
-    // (global_load ... saddr: one shift instead of four 64-bit address computations per gather)
-    const char* const d00 = (const char*)V.data;
-    const char* const d10 = d00 + 4u * (unsigned)V.sy;
-    const char* const d01 = d00 + 4u * (unsigned)V.sz;
-    const char* const d11 = d01 + 4u * (unsigned)V.sy;
-    if (interior) {
-      const unsigned off = (unsigned)base << 2;
-      tp.a = ld_pair((const float*)(d00 + off)); tp.b = ld_pair((const float*)(d10 + off));
-      tp.e = ld_pair((const float*)(d01 + off)); tp.f = ld_pair((const float*)(d11 + off));
+    FlatRay r;
+    {
+      const Ray3 p = ld3(a.pos, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vel, i, a.io_half, &a.vol, RAY_VEL);
+      flat_begin<PAIR>(V, R, r, p, u);
     }
     for (int it = 0; it < a.max_steps; ++it) {
-      if (inside) {                                                                         // masked gather (Q4)
-        if (!interior) {                          // boundary cell: clamp offsets from the position, taps fetched here
-          const Cell cb = locate(V, x, y, z);
-          tp = fetch(V.data, cb);
-        }
-        const Sample q = interp<false>(tp, wx, wy, wz);
-        const float gx = q.gx * V.inv_h, gy = q.gy * V.inv_h, gz = q.gz * V.inv_h;
-        const float dsn = a.ds * q.n;
-        vx = fmaf(dsn, gx, vx); vy = fmaf(dsn, gy, vy); vz = fmaf(dsn, gz, vz);             // :70
-      }
-      x = fmaf(a.ds, vx, x); y = fmaf(a.ds, vy, y); z = fmaf(a.ds, vz, z);                  // :71
-      // locate() in place
-      const float fx = x * V.inv_h, fy = y * V.inv_h, fz = z * V.inv_h;
-      const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-      wx = fx - flx; wy = fy - fly; wz = fz - flz;
-      const int ix = f2i_sat(flx), iy = f2i_sat(fly), iz = f2i_sat(flz);
-      const bool was_interior = interior;
-      interior = (((unsigned)ix - 1u) < V.lx) & (((unsigned)iy - 1u) < V.ly) & (((unsigned)iz - 1u) < V.lz);
-      bool cur_inside = true, esc_now = false;
-      if (interior) {
-        const int nb = mad24(iz, V.sz, mad24(iy, V.sy, ix));
-        if (!(was_interior & (nb == base))) {
-          __builtin_assume(nb >= 0 && nb < (1 << 29));
-          const unsigned off = (unsigned)nb << 2;
-          tp.a = ld_pair((const float*)(d00 + off)); tp.b = ld_pair((const float*)(d10 + off));
-          tp.e = ld_pair((const float*)(d01 + off)); tp.f = ld_pair((const float*)(d11 + off));
-        }
-        base = nb;
-      } else {
-        cur_inside = inbounds(V, x, y, z);                                                  // :73
-        esc_now = escaped(V, x, y, z, vx, vy, vz);                                          // :76
-      }
-      const bool cross = inside & !cur_inside;                                              // :74
-      esc = esc | cross | esc_now;                                                          // :75-76
-      if (cross) { xtx = x; xty = y; xtz = z; vtx = vx; vty = vy; vtz = vz; }               // :79-80
-      inside = cur_inside;                                                                  // :86
-      ++steps;
-      if (esc) break;                                                                       // per-ray form of :82
+      if (flat_advance<PAIR>(V, a.ds, it, r)) gather_rows<PAIR>(R, r.off, r.q0, r.q1);
+      if (!r.live) break;
     }
-    if (!esc) { xtx = x; xty = y; xtz = z; failed = 1u; }                                   // :95 (vt stays, Q6)
+    const bool esc = !r.live;
+    if (!esc) { r.steps = a.max_steps > 0 ? (unsigned)a.max_steps : 0u; failed = 1u; }
+    steps = r.steps;
+    float xtx = r.x, xty = r.y, xtz = r.z, vtx = r.vx, vty = r.vy, vtz = r.vz;
+    if (!(esc & r.crossed)) {
+      // escaped without crossing out of the box (never entered it): the record is the initial state (:56-57);
+      // ran out of steps: xt is the final position (:95), vt stays the initial direction (Q6)
+      const Ray3 p = ld3(a.pos, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vel, i, a.io_half, &a.vol, RAY_VEL);
+      if (esc) { xtx = p.x; xty = p.y; xtz = p.z; }
+      vtx = u.x; vty = u.y; vtz = u.z;
+    }
     st3(a.xt, i, xtx, xty, xtz, a.io_half, &a.vol, RAY_POS);
     st3(a.vt, i, vtx, vty, vtz, a.io_half, &a.vol, RAY_VEL);
   }
@@ -531,7 +619,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
 // when the window is flushed into the fp32 grid.
 typedef double win_t;
 #ifndef DRRT_WIN
-#define DRRT_WIN 10
+#define DRRT_WIN 9     // measured on MI355X (256^3 / 1M rays, same box): 7 -> 6.75 ms, 8 -> 6.08, 9 -> 4.94, 10 -> 5.23
 #endif
 #ifndef DRRT_WIN_PAD
 #define DRRT_WIN_PAD 1
@@ -550,28 +638,38 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // Flush the wave's window into the global grid and leave it zeroed.  Called with all 64 lanes.
-// Lanes are laid out as 4 window rows x 16 x-slots (kWinX <= 16 of them used), so a pass covers 4 (ly, lz) rows and
-// all addresses advance by constants -- no index decoding per slot (the flush runs every ~15 steps of a wave; a flat
-// "k -> (lx, ly, lz)" decode cost ~450 VALU instructions per flush, this one ~180).
+// The window's rows (a row = the kWinX slots of one (ly, lz)) are contiguous in LDS at pitch kWinPX, so the flush walks
+// them linearly: a pass covers 64 / kWinX rows (lane -> row lane / kWinX, slot lane % kWinX), the LDS address advances
+// by a constant and the grid address by a constant plus a wrap from one z-slice to the next.  Passes go in batches of
+// four: the four LDS exchanges are issued before the first result is used, so a flush costs ceil(rows / 7 / 4) LDS
+// round trips (3 for a 9^3 window) instead of one per pass.
 __device__ __forceinline__ void win_flush(win_t* win, int ox, int oy, int oz, float* __restrict__ grad,
                                           const Vol& V, int lane, bool no_global = false) {
-  static_assert(kWinX <= 16, "win_flush maps 16 lanes to one window row");
+  constexpr int kRowsPerPass = kWave / kWinX, kRowsTotal = kWinY * kWinZ;
+  constexpr int kPasses = (kRowsTotal + kRowsPerPass - 1) / kRowsPerPass, kBatch = 4;
+  static_assert(kWinX <= 16 && kRowsPerPass <= kWinY, "win_flush: one pass must not span more than two z-slices");
   wave_lds_fence();
-  const int lx = lane & 15, rsub = lane >> 4;
-  const bool xok = lx < kWinX;
-  win_t* wl = win + rsub * kWinSY + lx;                                  // slot of (lx, ly = rsub, lz = 0)
-  float* gl = grad + ((unsigned)oz * (unsigned)V.sz + (unsigned)(oy + rsub) * (unsigned)V.sy + (unsigned)(ox + lx));
+  const int rsub = lane / kWinX, lx = lane - rsub * kWinX;
+  const bool lane_ok = rsub < kRowsPerPass;
+  int r = rsub, ly = rsub;                                               // row index, its ly (lz = 0: kRowsPerPass <= kWinY)
+  win_t* wl = win + rsub * kWinPX + lx;
+  unsigned go = (unsigned)oz * (unsigned)V.sz + (unsigned)(oy + rsub) * (unsigned)V.sy + (unsigned)(ox + lx);
+  const unsigned step_y = (unsigned)kRowsPerPass * (unsigned)V.sy, wrap = (unsigned)V.sz - (unsigned)kWinY * (unsigned)V.sy;
 #pragma unroll 1
-  for (int lz = 0; lz < kWinZ; ++lz) {
+  for (int p0 = 0; p0 < kPasses; p0 += kBatch) {
+    win_t v[kBatch];
+    unsigned g[kBatch];
 #pragma unroll
-    for (int ly0 = 0; ly0 < kWinY; ly0 += 4) {
-      if (xok & (ly0 + rsub < kWinY)) {
-        // ds_wrxchg_rtn_b64: read the accumulated value and reset the slot in one LDS op
-        const win_t v = __hip_atomic_exchange(wl + ly0 * kWinSY, (win_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (v != (win_t)0 && !no_global) atomic_add_f32(gl + (unsigned)ly0 * (unsigned)V.sy, (float)v);
-      }
+    for (int b = 0; b < kBatch; ++b) {
+      v[b] = (win_t)0; g[b] = go;
+      // ds_wrxchg_rtn_b64: read the accumulated value and reset the slot in one LDS op
+      if (lane_ok & (r < kRowsTotal)) v[b] = __hip_atomic_exchange(wl, (win_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      r += kRowsPerPass; wl += kRowsPerPass * kWinPX; ly += kRowsPerPass; go += step_y;
+      if (ly >= kWinY) { ly -= kWinY; go += wrap; }
     }
-    wl += kWinSZ; gl += V.sz;
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b)
+      if (v[b] != (win_t)0 && !no_global) atomic_add_f32(grad + g[b], (float)v[b]);
   }
   wave_lds_fence();
 }
@@ -912,7 +1010,12 @@ __device__ __forceinline__ int win_index(int wox, int woy, int woz, int cx, int 
   const int lx = cx - wox, ly = cy - woy, lz = cz - woz;
   const bool in = ((unsigned)lx < (unsigned)(kWinX - 1)) & ((unsigned)ly < (unsigned)(kWinY - 1)) &
                   ((unsigned)lz < (unsigned)(kWinZ - 1));
-  return in ? mad24(lz, kWinSZ, mad24(ly, kWinSY, lx)) : -1;
+  // v_mad_u32_u24 by hand: with constant strides the compiler turns the 24-bit multiply into the quarter-rate
+  // v_mul_lo_u32 (lx, ly, lz are small and non-negative whenever the result is used)
+  int r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(ly), "s"(kWinSY), "v"(lx));
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(lz), "s"(kWinSZ), "v"(r));
+  return in ? r : -1;
 }
 
 // all 8 accumulated corners of the regular cell `base` (window slot lidx, or -1: straight to the grid)
@@ -941,8 +1044,11 @@ __device__ __forceinline__ bool flat_emit8(win_t* win, float* grad, int sy, int 
   return false;
 }
 
-template <bool ABL>
-__global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
+#ifndef DRRT_ADJ_WAVES
+#define DRRT_ADJ_WAVES 1
+#endif
+template <bool ABL, bool PAIR>   // PAIR: gather from the pair copy of the grid (two 16-byte loads per cell, see gather_rows)
+__global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackArgs a) {
   __shared__ win_t s_win[kWavesPerBlock][kWinFloats];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   win_t* win = s_win[wid];
@@ -962,20 +1068,46 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
   }
   const int experiment = ABL ? a.experiment : 0;
   int wox = -(1 << 28), woy = -(1 << 28), woz = -(1 << 28);   // window origin (wave-uniform); far away = nothing is inside
-  // the cell the ray stands on: coordinates of corner 000, flat index, regular (no clamped neighbour), window slot
-  Cell c;
-  c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0; c.wx = c.wy = c.wz = 0.f; c.interior = false;
-  bool regular = false;
+  // the cell the ray stands on, located IN PLACE: flat index and coordinates of corner 000, in-cell fractions, strictly
+  // interior / regular (no clamped neighbour), window slot.  A boundary cell's clamp offsets are not carried: the
+  // boundary branch at the top of the step re-derives them from the position (locate()).
+  int base = 0, ix = 0, iy = 0, iz = 0;
+  float wx = 0.f, wy = 0.f, wz = 0.f;
+  bool interior = false, regular = false;
   int lidx = -1;
-  TapCache tc;
-  tc.base = -1; tc.t = taps_zero();
-  f2 p00 = f2{0.f, 0.f}, p10 = p00, p01 = p00, p11 = p00;   // accumulators of cell c: x-pairs at (y0,z0) (y1,z0) (y0,z1) (y1,z1)
+  f4 q0 = f4{0.f, 0.f, 0.f, 0.f}, q1 = q0;                   // the taps, as gathered (gather_rows)
+  int tbase = -1;                                            // cell whose taps the lane holds (-1: none)
+  f2 p00 = f2{0.f, 0.f}, p10 = p00, p01 = p00, p11 = p00;   // accumulators of the cell: x-pairs at (y0,z0) (y1,z0) (y0,z1) (y1,z1)
   bool miss = false;                                         // the cell just entered lies outside the window
+  const TapRows R = tap_rows<PAIR>(V);                       // wave-uniform row pointers + ONE 32-bit byte offset per lane
+  // step to the next sample (:420), locate its cell in place and issue its gather unless the lane holds those taps
+#define DRRT_FLAT_STEP_LOCATE()                                                                                        \
+  do {                                                                                                                 \
+    s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);                          \
+    const float fx_ = s.x * V.inv_h, fy_ = s.y * V.inv_h, fz_ = s.z * V.inv_h;                                         \
+    ix = cvt_floor_i32(fx_); iy = cvt_floor_i32(fy_); iz = cvt_floor_i32(fz_);                                         \
+    interior = (((unsigned)ix - 1u) < V.lx) & (((unsigned)iy - 1u) < V.ly) & (((unsigned)iz - 1u) < V.lz);             \
+    if (interior) {                                                                                                    \
+      /* v_fract == f - floor(f) bit for bit for the non-negative coordinates of an interior cell */                    \
+      wx = __builtin_amdgcn_fractf(fx_); wy = __builtin_amdgcn_fractf(fy_); wz = __builtin_amdgcn_fractf(fz_);         \
+      nbase = mad24(iz, V.sz, mad24(iy, V.sy, ix));                                                                    \
+      nregular = true;                                                                                                 \
+      if (nbase != tbase) {                                                                                            \
+        __builtin_assume(nbase >= 0 && nbase < (1 << 29));                                                             \
+        gather_rows<PAIR>(R, tap_offset<PAIR>(nbase), q0, q1);                                                         \
+        tbase = nbase;                                                                                                 \
+      }                                                                                                                \
+    } else {                                                                                                           \
+      const Cell cb_ = locate(V, s.x, s.y, s.z);                                                                       \
+      wx = cb_.wx; wy = cb_.wy; wz = cb_.wz; ix = cb_.ix; iy = cb_.iy; iz = cb_.iz; nbase = cb_.base;                   \
+      nregular = (cb_.ox == 1) & (cb_.oy == V.sy) & (cb_.oz == V.sz);                                                  \
+      tbase = -1;                                                                                                      \
+    }                                                                                                                  \
+  } while (0)
   if (s.active) {
-    s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);   // :420, first sample
-    c = locate(V, s.x, s.y, s.z);
-    regular = (c.ox == 1) & (c.oy == V.sy) & (c.oz == V.sz);
-    prefetch_taps(V, c, tc);
+    int nbase; bool nregular;
+    DRRT_FLAT_STEP_LOCATE();                                 // first sample
+    base = nbase; regular = nregular;
     miss = regular;                                          // no window yet
   }
   bool dirty = false;
@@ -993,7 +1125,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
       const int first = __ffsll((long long)cm) - 1, last = 63 - __clzll((long long)cm);
       int ref = (first + last) >> 1;
       if (!((cm >> ref) & 1ull)) ref = first;
-      const int rx = __shfl(c.ix, ref, kWave), ry = __shfl(c.iy, ref, kWave), rz = __shfl(c.iz, ref, kWave);
+      const int rx = __shfl(ix, ref, kWave), ry = __shfl(iy, ref, kWave), rz = __shfl(iz, ref, kWave);
       const float dx_ = -__shfl(s.vx, ref, kWave), dy_ = -__shfl(s.vy, ref, kWave), dz_ = -__shfl(s.vz, ref, kWave);
       const float inv_dm = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f)));   // placement only
       const float fx = 0.5f - 0.35f * (dx_ * inv_dm), fy = 0.5f - 0.35f * (dy_ * inv_dm), fz = 0.5f - 0.35f * (dz_ * inv_dm);
@@ -1003,7 +1135,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
       ox = max(0, min(ox, V.W - kWinX)); oy = max(0, min(oy, V.H - kWinY)); oz = max(0, min(oz, V.D - kWinZ));
       wox = __builtin_amdgcn_readfirstlane(ox); woy = __builtin_amdgcn_readfirstlane(oy);
       woz = __builtin_amdgcn_readfirstlane(oz);
-      lidx = regular ? win_index(wox, woy, woz, c.ix, c.iy, c.iz) : -1;       // every lane's cell, in the new window
+      lidx = regular ? win_index(wox, woy, woz, ix, iy, iz) : -1;             // every lane's cell, in the new window
       miss = s.active & regular & (lidx < 0);
       cooldown = (__ballot(miss) != 0ull) ? 4 : 0;                            // incoherent wave: do not thrash
     } else if (cooldown > 0) {
@@ -1011,36 +1143,39 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
     }
     bool used_lds = false;
     if (s.active) {
-      if (!c.interior) tc.t = fetch(V.data, c);          // boundary cell (clamped neighbours): fetched here, not ahead
+      if (!interior) taps_set<PAIR>(fetch(V.data, locate(V, s.x, s.y, s.z)), q0, q1);   // boundary cell (clamped neighbours): fetched here, not ahead
+      Cell c;                                              // what adj_sample reads of the cell: fractions, interior
+      c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0;
+      c.wx = wx; c.wy = wy; c.wz = wz; c.interior = interior;
+      const float px = s.x, py = s.y, pz = s.z;            // position of this sample (the clamped splat re-locates it)
       AdjSample m;
-      if (!adj_sample<0>(V, nullptr, a.ds, s, c, tc.t, m)) {
+      if (!adj_sample<0>(V, nullptr, a.ds, s, c, taps_of<PAIR>(q0, q1), m)) {
         // the ray has ended (:426-428): it contributes nothing here; hand over what its cell has accumulated
-        if (regular && experiment != 1) used_lds = flat_emit8(win, a.grad, V.sy, V.sz, lidx, c.base, p00, p10, p01, p11);
+        if (regular && experiment != 1) used_lds = flat_emit8(win, a.grad, V.sy, V.sz, lidx, base, p00, p10, p01, p11);
       } else {
         ++steps;
-        Corners w;
         {
           // first half of adj_contrib: the 8 splat weights (they need the in-cell fractions of THIS cell)
           const float dn = dot3(s.mx, s.my, s.mz, m.gx, m.gy, m.gz);                            // :430
           const float nds = (m.n * a.ds) * a.grad_scale;
           if (regular) {
-            const CornerPairs cp = splat_weights_pk(c.wx, c.wy, c.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);   // :431-432
+            const CornerPairs cp = splat_weights_pk(wx, wy, wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);   // :431-432
             p00 += cp.c00; p10 += cp.c10; p01 += cp.c01; p11 += cp.c11;
           } else if (experiment != 2 && experiment != 1) {
-            w = splat_weights(c.wx, c.wy, c.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);
             // clamped boundary cell: taps coincide; straight to the grid
-            float* g = a.grad + c.base;
-            atomic_add_f32(g, w.c000);                    atomic_add_f32(g + c.ox, w.c100);
-            atomic_add_f32(g + c.oy, w.c010);             atomic_add_f32(g + c.oy + c.ox, w.c110);
-            atomic_add_f32(g + c.oz, w.c001);             atomic_add_f32(g + c.oz + c.ox, w.c101);
-            atomic_add_f32(g + c.oz + c.oy, w.c011);      atomic_add_f32(g + c.oz + c.oy + c.ox, w.c111);
+            const Cell cb = locate(V, px, py, pz);
+            const Corners w = splat_weights(cb.wx, cb.wy, cb.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);
+            float* g = a.grad + cb.base;
+            atomic_add_f32(g, w.c000);                     atomic_add_f32(g + cb.ox, w.c100);
+            atomic_add_f32(g + cb.oy, w.c010);             atomic_add_f32(g + cb.oy + cb.ox, w.c110);
+            atomic_add_f32(g + cb.oz, w.c001);             atomic_add_f32(g + cb.oz + cb.ox, w.c101);
+            atomic_add_f32(g + cb.oz + cb.oy, w.c011);     atomic_add_f32(g + cb.oz + cb.oy + cb.ox, w.c111);
           }
           // step to the next sample and issue its gather (it + 1 == max_steps: located and fetched, never used)
-          s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);   // :420
-          const int old_base = c.base, old_lidx = lidx;
+          const int old_base = base, old_lidx = lidx;
           const bool old_regular = regular;
-          c = locate(V, s.x, s.y, s.z);
-          prefetch_taps(V, c, tc);
+          int nbase; bool nregular;
+          DRRT_FLAT_STEP_LOCATE();
           // second half of adj_contrib: lambda / mu (:434-435)
           const float hxy = m.hxy * V.inv_h2, hxz = m.hxz * V.inv_h2, hyz = m.hyz * V.inv_h2;
           const float hmx = fmaf(hxz, s.mz, hxy * s.my);
@@ -1051,9 +1186,9 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
           s.lz = fmaf(a.ds, fmaf(dn, m.gz, m.n * hmz), s.lz);
           s.mx = fmaf(a.ds, s.lx, s.mx); s.my = fmaf(a.ds, s.ly, s.my); s.mz = fmaf(a.ds, s.lz, s.mz);
           // ---- the ray leaves its cell ----
-          if (c.base != old_base || !c.interior) {
-            regular = c.interior | ((c.ox == 1) & (c.oy == V.sy) & (c.oz == V.sz));
-            const int d = c.base - old_base;
+          if (nbase != old_base || !interior) {
+            base = nbase; regular = nregular;
+            const int d = nbase - old_base;
             if (d != 0 || regular != old_regular) {
               const bool ax = (d == 1) | (d == -1), ay = (d == V.sy) | (d == -V.sy), az = (d == V.sz) | (d == -V.sz);
               if (old_regular) {
@@ -1104,13 +1239,16 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
                       const float s3 = q3 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q3), 0x4E, 0xF, 0xF, false));
                       const unsigned ql = threadIdx.x & 3u;
                       const bool add = same ? ql == 0u : (psame ? (ql & 1u) == 0u : true);
-                      if (add) {
+                      if (experiment == 6) {            // ablation: no pre-reduction, every lane adds its own values
+                        win_t* q = win + qi;
+                        atomicAdd(q, (win_t)e0); atomicAdd(q + lp, (win_t)e1); atomicAdd(q + lq, (win_t)e2); atomicAdd(q + lq + lp, (win_t)e3);
+                      } else if (add) {
                         win_t* q = win + qi;
                         atomicAdd(q, (win_t)(same ? s0 : (psame ? q0 : e0)));      atomicAdd(q + lp, (win_t)(same ? s1 : (psame ? q1 : e1)));
                         atomicAdd(q + lq, (win_t)(same ? s2 : (psame ? q2 : e2))); atomicAdd(q + lq + lp, (win_t)(same ? s3 : (psame ? q3 : e3)));
                       }
                     }
-                    used_lds = true;
+                    used_lds = experiment != 5;         // ablation 5: never flush (until the end)
                   } else if (experiment != 2) {
                     float* g = a.grad + old_base + (fwd ? 0 : ga);
                     atomic_add_f32(g, e0); atomic_add_f32(g + gp, e1); atomic_add_f32(g + gq, e2); atomic_add_f32(g + gq + gp, e3);
@@ -1121,7 +1259,7 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
                   p00 = p10 = p01 = p11 = f2{0.f, 0.f};
                 }
               }
-              lidx = regular ? win_index(wox, woy, woz, c.ix, c.iy, c.iz) : -1;
+              lidx = regular ? win_index(wox, woy, woz, ix, iy, iz) : -1;
               miss = regular & (lidx < 0);
             }
           }
@@ -1130,8 +1268,9 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_flat(BackArgs a) {
     }
     dirty = dirty | (__ballot(used_lds) != 0ull);
   }
+#undef DRRT_FLAT_STEP_LOCATE
   // rays still marching when max_steps ran out keep what their cell has accumulated: hand it over
-  if (s.active && regular && experiment != 1) { if (flat_emit8(win, a.grad, V.sy, V.sz, lidx, c.base, p00, p10, p01, p11)) dirty = true; }
+  if (s.active && regular && experiment != 1) { if (flat_emit8(win, a.grad, V.sy, V.sz, lidx, base, p00, p10, p01, p11)) dirty = true; }
   dirty = __ballot(dirty) != 0ull;
   if (dirty) { win_flush(win, wox, woy, woz, a.grad, V, lane, experiment == 2); ++n_flush; }
   if (ABL && a.dbg) {
@@ -1355,41 +1494,41 @@ extern "C" size_t drrt_workspace_bytes(size_t n, unsigned flags) {
   return b;
 }
 
-// Workspace layout: [ sort buffers | trace_target state ][ quad copy of the grid, 16 B per voxel ][ 512 B counters ]
+// Workspace layout: [ sort buffers | trace_target state ][ pair copy of the grid, 8 B per voxel ][ 512 B counters ]
 extern "C" size_t drrt_workspace_bytes_grid(size_t n, long long nvox, unsigned flags) {
   size_t b = drrt_workspace_bytes(n, flags);
-  if ((flags & DRRT_FLAG_QUAD_GRID) && nvox > 0) b += (size_t)nvox * sizeof(float4);
+  if ((flags & DRRT_FLAG_PAIR_GRID) && nvox > 0) b += (size_t)nvox * 2 * sizeof(float);
   return b + 512;
 }
 
 namespace drrt {
-// quad[i] = {n[i], n[i+1], n[i+W], n[i+W+1]}, neighbours clamped at the far x / y faces (those quads are
-// never read: only strictly interior cells use the copy).  One thread per voxel, 4+16 B of traffic each.
-__global__ void __launch_bounds__(256) k_build_quad(const float* __restrict__ g, float4* __restrict__ q, int W, int H,
+// pair[2 i] = n[i], pair[2 i + 1] = n[i + W] (the y-neighbour, clamped at the far y face -- those entries are never
+// read: only strictly interior cells use the copy).  One thread per voxel, 4 + 8 B of traffic each.
+__global__ void __launch_bounds__(256) k_build_pair(const float* __restrict__ g, float2* __restrict__ q, int W, int H,
                                                     unsigned nvox) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= nvox) return;
-  const unsigned row = i / (unsigned)W, x = i - row * (unsigned)W, y = row % (unsigned)H;
-  const unsigned x1 = (x + 1u < (unsigned)W) ? 1u : 0u, y1 = (y + 1u < (unsigned)H) ? (unsigned)W : 0u;
-  q[i] = make_float4(g[i], g[i + x1], g[i + y1], g[i + y1 + x1]);
+  const unsigned row = i / (unsigned)W, y = row % (unsigned)H;
+  const unsigned y1 = (y + 1u < (unsigned)H) ? (unsigned)W : 0u;
+  q[i] = make_float2(g[i], g[i + y1]);
 }
 }  // namespace drrt
 
-// DRRT_FLAG_QUAD_GRID: place (and, unless DRRT_FLAG_QUAD_REUSE, build) the quad copy in the workspace.
-static int maybe_quad(Vol& V, long long nvox, size_t n, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s) {
-  if (!(flags & DRRT_FLAG_QUAD_GRID)) return DRRT_OK;
-  const size_t off = drrt_workspace_bytes(n, flags), need = off + (size_t)nvox * sizeof(float4) + 512;
-  if (!ws || ws_bytes < need) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_QUAD_GRID (see drrt_workspace_bytes_grid)");
-  if (((uintptr_t)ws + off) % 16 != 0) return fail(DRRT_ERR_ARG, "workspace must be 16-byte aligned for DRRT_FLAG_QUAD_GRID");
-  float4* q = (float4*)((char*)ws + off);
-  if (!(flags & DRRT_FLAG_QUAD_REUSE)) {
+// DRRT_FLAG_PAIR_GRID: place (and, unless DRRT_FLAG_PAIR_REUSE, build) the pair copy in the workspace.
+static int maybe_pair(Vol& V, long long nvox, size_t n, unsigned flags, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!(flags & DRRT_FLAG_PAIR_GRID)) return DRRT_OK;
+  const size_t off = drrt_workspace_bytes(n, flags), need = off + (size_t)nvox * 2 * sizeof(float) + 512;
+  if (!ws || ws_bytes < need) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_PAIR_GRID (see drrt_workspace_bytes_grid)");
+  if (((uintptr_t)ws + off) % 16 != 0) return fail(DRRT_ERR_ARG, "workspace must be 16-byte aligned for DRRT_FLAG_PAIR_GRID");
+  float2* q = (float2*)((char*)ws + off);
+  if (!(flags & DRRT_FLAG_PAIR_REUSE)) {
     ProfScope prof(DRRT_PROF_QUAD, s);
-    hipLaunchKernelGGL(drrt::k_build_quad, dim3((unsigned)(((size_t)nvox + 255) / 256)), dim3(256), 0, s, V.data, q, V.W, V.H,
+    hipLaunchKernelGGL(drrt::k_build_pair, dim3((unsigned)(((size_t)nvox + 255) / 256)), dim3(256), 0, s, V.data, q, V.W, V.H,
                        (unsigned)nvox);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail_hip(e, "k_build_quad");
+    if (e != hipSuccess) return fail_hip(e, "k_build_pair");
   }
-  V.quad = q;
+  V.pair = (const float*)q;
   return DRRT_OK;
 }
 
@@ -1482,7 +1621,7 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
   rc = zero_stats(stats, s); if (rc) return rc;
   rc = maybe_sort(a.vol, h, n, pos, vel, 1.f, flags, ws, ws_bytes, &a.perm, s, hint, io_half); if (rc) return rc;
-  if (!(flags & DRRT_FLAG_LDS_BRICKS)) { rc = maybe_quad(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc; }
+  if (!(flags & DRRT_FLAG_LDS_BRICKS)) { rc = maybe_pair(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc; }
   if (MODE == 2) {                      // n flag bytes, in the slack the workspace keeps after the sort buffers
     const size_t off = (flags & DRRT_FLAG_SORT_RAYS) ? align_up(sort_workspace_bytes(n), 256) : 0;
     if (!ws || ws_bytes < off + n) return fail(DRRT_ERR_ARG, "workspace too small for trace_sdf (see drrt_workspace_bytes)");
@@ -1496,8 +1635,10 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
     ProfScope prof(DRRT_PROF_TRACE, s);
     if (MODE == 2 || !(flags & DRRT_FLAG_LDS_BRICKS)) {
       const unsigned reuse = (flags & DRRT_FLAG_TAP_REUSE_MASK);
-      if (MODE == 0 && reuse == 0 && !(flags & (DRRT_FLAG_QUAD_GRID | DRRT_FLAG_LEGACY_FORWARD)))
-        hipLaunchKernelGGL(k_trace_flat, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      if (MODE == 0 && reuse == 0 && !(flags & DRRT_FLAG_LEGACY_FORWARD)) {
+        if (a.vol.pair != nullptr) hipLaunchKernelGGL(k_trace_flat<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+        else                       hipLaunchKernelGGL(k_trace_flat<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      }
       else if (reuse == DRRT_FLAG_TAP_REUSE_OFF)
         hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
       else if (reuse == DRRT_FLAG_TAP_REUSE_FACE)
@@ -1669,7 +1810,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   if (!xt || !vt || !dx || !dv) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
   rc = maybe_sort(a.vol, h, n, xt, vt, -1.f, flags, ws, ws_bytes, &a.perm, s, hint, io_half); if (rc) return rc;
-  rc = maybe_quad(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc;
+  rc = maybe_pair(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc;
   a.io_half = io_half;
   a.sdf = sdf; a.xt = xt; a.vt = vt; a.dx = dx; a.dv = dv; a.grad = grad; a.stats = stats;
   a.n = n; a.ds = ds; a.max_steps = steps_adj(h, res, ds);
@@ -1686,11 +1827,13 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
     ProfScope prof(DRRT_PROF_BACKTRACE, s);
     if (flags & DRRT_FLAG_DIRECT_ATOMICS)
       hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
-    else if (MODE == 0 && !(flags & DRRT_FLAG_LEGACY_ADJOINT) && !(flags & DRRT_FLAG_QUAD_GRID)) {
-      if (a.experiment != 0 || a.dbg != nullptr)
-        hipLaunchKernelGGL((k_backtrace_flat<true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
-      else
-        hipLaunchKernelGGL((k_backtrace_flat<false>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+    else if (MODE == 0 && !(flags & DRRT_FLAG_LEGACY_ADJOINT)) {
+      const bool abl = a.experiment != 0 || a.dbg != nullptr, pair = a.vol.pair != nullptr;
+      const dim3 g(grid_for(n));
+      if (abl) { if (pair) hipLaunchKernelGGL((k_backtrace_flat<true, true>), g, dim3(kBlock), 0, s, a);
+                 else      hipLaunchKernelGGL((k_backtrace_flat<true, false>), g, dim3(kBlock), 0, s, a); }
+      else     { if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true>), g, dim3(kBlock), 0, s, a);
+                 else      hipLaunchKernelGGL((k_backtrace_flat<false, false>), g, dim3(kBlock), 0, s, a); }
     }
     else if (a.experiment != 0 || a.dbg != nullptr)
       hipLaunchKernelGGL((k_backtrace_win<MODE, true, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);

@@ -34,10 +34,20 @@ class Options:
     direct_atomics: bool = False  # adjoint: one global atomic per tap (debug / A-B)
     legacy_adjoint: bool = False  # adjoint: the round-1 window kernel instead of k_backtrace_flat (DRRT_FLAG_LEGACY_ADJOINT, A-B)
     lds_bricks: bool = False      # forward: opt-in LDS-staged bricks of the grid (bit-identical; slower on MI355X)
-    quad_grid: object = False     # opt-in 16-byte "quad" copy of the grid in the workspace (DRRT_FLAG_QUAD_GRID):
-                                  # True, False, or "auto" = when the call does enough ray-steps per voxel to pay
-                                  # for the copy.  Bit-identical; measured +7 % on the forward kernel and +0.7 %
-                                  # on the whole fwd+adjoint step of the 256^3 / 1M-ray benchmark
+    pair_grid: object = "auto"    # the "pair copy" of the grid in the workspace (DRRT_FLAG_PAIR_GRID; 8 bytes per voxel, two
+                                  # 16-byte gathers per cell instead of four 8-byte ones).  True, False, or "auto" = a
+                                  # forward march builds it when the call keeps the whole GPU busy and does enough
+                                  # ray-steps per voxel to pay for the copy, and the adjoint paired with that forward
+                                  # reuses it.  Bit-identical; 256^3 / 1M rays: forward 1.31 -> 1.06 ms (+0.05 ms for the
+                                  # copy), adjoint -2 %
+
+    @property
+    def quad_grid(self):          # round-1 name
+        return self.pair_grid
+
+    @quad_grid.setter
+    def quad_grid(self, v):
+        self.pair_grid = v
 
 
 options = Options()
@@ -82,39 +92,51 @@ def _workspace(n: int, flags: int, device: torch.device, nvox: int = 0) -> torch
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
         _quad_tokens.pop(key, None)
-    if not (flags & _lib.FLAG_QUAD_GRID):
-        _quad_tokens.pop(key, None)             # this call may overwrite the region a quad copy lived in
+    if not (flags & _lib.FLAG_PAIR_GRID):
+        _quad_tokens.pop(key, None)             # this call may overwrite the region a pair copy lived in
     return ws
 
 
-# What the quad copy in a device's workspace was built from: (rif tensor, key).  Holding the tensor keeps its
+# What the pair copy in a device's workspace was built from: (rif tensor, key).  Holding the tensor keeps its
 # storage alive, so equal (data_ptr, version counter) means "same contents"; n and the sort bit fix where in
 # the workspace the copy lives.
 _quad_tokens: Dict[tuple, tuple] = {}
 
 
 def _march_workspace(rif_: torch.Tensor, res, n: int, h: float, ds: float, flags: int, device: torch.device,
-                     paired: bool = False):
-    """Workspace + final flags of a grid march call: decides on DRRT_FLAG_QUAD_GRID (options.quad_grid).
+                     paired: bool = False, adjoint: bool = False):
+    """Workspace + final flags of a grid march call: decides on DRRT_FLAG_PAIR_GRID (options.pair_grid).
     Forward calls always rebuild the copy.  An adjoint the caller explicitly pairs with its forward
-    (`paired`: it passed the forward's visit order) adds DRRT_FLAG_QUAD_REUSE when the workspace still holds the
+    (`paired`: it passed the forward's visit order) adds DRRT_FLAG_PAIR_REUSE when the workspace still holds the
     copy built from this very tensor (same storage, same version counter, same layout) and no other call has
-    used the workspace since."""
-    q = options.quad_grid
-    if q == "auto":
-        # the copy moves 20 B per voxel and saves about one 8-byte gather pair per ray-step
+    used the workspace since.  With "auto" an adjoint never builds the copy itself (it gains ~2 %, less than the
+    copy costs): it uses it only when it can reuse the forward's."""
+    q = options.pair_grid
+    auto = q == "auto"
+    if auto:
+        # the copy moves 12 B per voxel; the gathers it halves only bound the march when the GPU is full of waves
         ok = float(ds) > 0.0 and float(h) > 0.0               # invalid steps are the library's to report
-        q = ok and n * max(int(r) for r in res) * (float(h) / float(ds)) >= 16.0 * rif_.numel()
+        q = ok and n >= _PAIR_AUTO_MIN_RAYS and \
+            n * max(int(r) for r in res) * (float(h) / float(ds)) >= 8.0 * rif_.numel()
     if not q or (flags & _lib.FLAG_LDS_BRICKS) or n == 0:
         return flags, _workspace(n, flags, device)
-    flags |= _lib.FLAG_QUAD_GRID
-    ws = _workspace(n, flags, device, rif_.numel())          # may reallocate -> drops the token
+    pflags = flags | _lib.FLAG_PAIR_GRID
     key = (rif_.data_ptr(), rif_._version, rif_.numel(), n, flags & _lib.FLAG_SORT_RAYS)
+    if auto and adjoint:
+        tok = _quad_tokens.get(_wkey(device))
+        need = int(_lib.load().drrt_workspace_bytes_grid(n, rif_.numel(), pflags))
+        ws = _workspaces.get(_wkey(device))
+        if not (paired and tok is not None and tok[1] == key and ws is not None and ws.numel() >= need):
+            return flags, _workspace(n, flags, device)
+    ws = _workspace(n, pflags, device, rif_.numel())         # may reallocate -> drops the token
     tok = _quad_tokens.get(_wkey(device))
     if paired and tok is not None and tok[1] == key:
-        flags |= _lib.FLAG_QUAD_REUSE
+        pflags |= _lib.FLAG_PAIR_REUSE
     _quad_tokens[_wkey(device)] = (rif_, key)
-    return flags, ws
+    return pflags, ws
+
+
+_PAIR_AUTO_MIN_RAYS = 384 * 1024     # about 6 resident waves per SIMD on 256 CUs
 
 
 def _dev(t: torch.Tensor) -> torch.device:
@@ -396,7 +418,7 @@ class TracerC:
             grad = torch.empty_like(rif_)
             fl = _flags(adjoint=True) | (_lib.FLAG_Q16_POS_ONLY if qpos else 0)
             q16 = q16 or qpos
-            (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None), _new_stats(dev)
+            (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None, adjoint=True), _new_stats(dev)
             fn = _lib.load().drrt_backtrace_q16io if q16 else (_lib.load().drrt_backtrace_f16io if half else _lib.load().drrt_backtrace_f32)
             try:
                 _hint(order, n)
@@ -419,7 +441,7 @@ class TracerC:
             vt_, dx_, dv_ = _rays(vt, dev, n), _rays(dx, dev, n), _rays(dv, dev, n)
             grad = torch.empty_like(rif_)
             fl = _flags(adjoint=True)
-            (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None), _new_stats(dev)
+            (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None, adjoint=True), _new_stats(dev)
             try:
                 _hint(order, n)
                 _lib.check(_lib.load().drrt_backtrace_sdf_f32(

@@ -73,8 +73,11 @@ def parse_args(argv=None):
     ap.add_argument("--lds-bricks", action="store_true", help="forward: opt-in LDS-staged grid bricks")
     ap.add_argument("--no-order-reuse", action="store_true",
                     help="adjoint computes its own visit order instead of reusing the forward's")
-    ap.add_argument("--quad", action="store_true", help="opt-in: build / use the 16-byte quad copy of the grid "
-                                                         "(DRRT_FLAG_QUAD_GRID; forward builds it, adjoint reuses it)")
+    ap.add_argument("--pair", choices=["auto", "on", "off"], default="auto",
+                    help="pair copy of the grid (DRRT_FLAG_PAIR_GRID: two 16-byte gathers per cell; the forward builds "
+                         "it -- inside the timed step -- and the adjoint reuses it).  auto = the rule of "
+                         "adjointnonlinearraytracing_amd.drrt (enough rays to fill the GPU, enough ray-steps per voxel)")
+    ap.add_argument("--quad", action="store_true", help="same as --pair on (round-1 name)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-counters", action="store_true", help="print LDS-window counters (stderr)")
     ap.add_argument("--experiment", type=int, default=0, help="development ablation id (0 = product)")
@@ -322,13 +325,21 @@ def run_rank(args) -> int:
     nvox = rif.numel()
     res = (C.c_int * 3)(R, R, R)
     flags = 0 if args.no_sort else _lib.FLAG_SORT_RAYS
-    if args.quad and not args.lds_bricks:
-        flags |= _lib.FLAG_QUAD_GRID                   # forward builds the quad copy, the paired adjoint reuses it
-    fflags = flags | (_lib.FLAG_LDS_BRICKS if args.lds_bricks else 0) | args.fwd_flags
-    aflags = flags | (_lib.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | args.adj_flags
-    if flags & _lib.FLAG_QUAD_GRID:
-        aflags |= _lib.FLAG_QUAD_REUSE
-    aflags |= (_lib.FLAG_DEBUG_COUNTERS if args.debug_counters else 0) | ((args.experiment & 0xff) << 8)
+    if args.quad:
+        args.pair = "on"
+    fflags0 = flags | (_lib.FLAG_LDS_BRICKS if args.lds_bricks else 0) | args.fwd_flags
+    aflags0 = flags | (_lib.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | args.adj_flags
+    aflags0 |= (_lib.FLAG_DEBUG_COUNTERS if args.debug_counters else 0) | ((args.experiment & 0xff) << 8)
+
+    def pair_flags(n):
+        """(forward flags, adjoint flags, pair copy in use) for a rank marching n rays: the forward builds the pair copy,
+        the paired adjoint reuses it; `auto` applies the product's own rule (drrt._march_workspace)."""
+        from adjointnonlinearraytracing_amd import drrt as _drrt
+        use = args.pair == "on" or (args.pair == "auto" and n >= _drrt._PAIR_AUTO_MIN_RAYS
+                                    and n * R * (h / ds) >= 8.0 * nvox)
+        if not use or args.lds_bricks or n == 0:
+            return fflags0, aflags0, False
+        return fflags0 | _lib.FLAG_PAIR_GRID, aflags0 | _lib.FLAG_PAIR_GRID | _lib.FLAG_PAIR_REUSE, True
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
     grad = torch.empty(nvox, dtype=torch.float32, device=dev)
@@ -349,7 +360,8 @@ def run_rank(args) -> int:
         else:
             pos, vel = (t.to(dev) for t in make_rays(args.rays, seed=rank))
         n = pos.shape[0]
-        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, nvox, flags)) + 1024, dtype=torch.uint8, device=dev)
+        fflags, aflags, pair = pair_flags(n)
+        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, nvox, fflags)) + 1024, dtype=torch.uint8, device=dev)
         xt, vt = torch.empty_like(pos), torch.empty_like(vel)
         dx, dv = torch.ones_like(pos), torch.ones_like(vel)          # adjoint seed dx=dv=1 (src/test.cpp:142-144)
         st_f = torch.zeros(3, dtype=torch.int64, device=dev)
@@ -403,7 +415,7 @@ def run_rank(args) -> int:
             return (sum(v) / len(v)) if v else float("nan")
         return dict(mode=mode, n=n, elapsed=elapsed, fwd_total=fwd_total, adj_total=adj_total, fwd_steps=fwd_steps,
                     adj_steps=adj_steps, n_failed=n_failed, ms_fwd=avg("trace"), ms_adj=avg("backtrace"),
-                    ms_sort=avg("sort"), ms_zero=avg("zero"), ms_quad=avg("quad"), ms_allreduce=ms_ar,
+                    ms_sort=avg("sort"), ms_zero=avg("zero"), ms_quad=avg("quad"), ms_allreduce=ms_ar, pair=pair,
                     pos=pos, vel=vel)
 
     modes = ["strong", "weak"] if args.scaling == "both" else [args.scaling]
@@ -417,7 +429,7 @@ def run_rank(args) -> int:
         ach_adj = adj_steps * B_ADJ / (ms_adj * 1e-3) / 1e9
         ach_fwd = fwd_steps * B_FWD / (ms_fwd * 1e-3) / 1e9
         default_cfg = (R == 256 and n == 1024 * 1024 and world == 1 and not args.no_sort and not args.direct_atomics
-                       and not args.experiment and not args.quad and not args.lds_bricks and not args.fwd_flags
+                       and not args.experiment and args.pair == "auto" and not args.lds_bricks and not args.fwd_flags
                        and not args.adj_flags)
         pmc, pmc_src = load_pmc() if default_cfg else (None, None)
         pk_adj = pmc_kernel(pmc, "drrt::k_backtrace_flat", "drrt::k_backtrace_win")
@@ -459,13 +471,13 @@ def run_rank(args) -> int:
                        "grid": R, "global_rays": int(args.rays if main_mode == "strong" else args.rays * world),
                        "rays_rank0": n, "fwd_ray_steps_rank0": fwd_steps, "adj_ray_steps_rank0": adj_steps,
                        "fwd_ray_steps_global": m["fwd_total"], "n_failed": m["n_failed"],
-                       "sort_rays": not args.no_sort, "quad_grid": bool(flags & _lib.FLAG_QUAD_GRID),
+                       "sort_rays": not args.no_sort, "pair_grid": bool(m["pair"]),
                        "parallelism": f"ray-shard x{world}", "backend": args.backend if use_dist else None,
                        "shard_of": args.shard_of or None},
             "roofline": roof,
             "roofline_fwd": roof_f,
             "phase_ms": {"sort_avg": m["ms_sort"], "zero_grid": m["ms_zero"],
-                         "quad_copy": None if m["ms_quad"] != m["ms_quad"] else m["ms_quad"],
+                         "pair_copy": None if m["ms_quad"] != m["ms_quad"] else m["ms_quad"],
                          "trace": ms_fwd, "backtrace": ms_adj, "allreduce": m["ms_allreduce"] if use_dist else None},
             "fwd_only_ray_steps_per_s_per_gpu": fwd_steps / (ms_fwd * 1e-3),
         }

@@ -64,15 +64,18 @@ extern "C" {
                                        read the taps from there instead of gathering from global
                                        memory every step.  Bit-identical results; measured slower than
                                        the default L1-served pair gathers on MI355X   */
-#define DRRT_FLAG_QUAD_GRID    64u  /* trace / trace_pln / trace_sdf / backtrace*: build a "quad" copy of the grid in
-                                       the workspace (16 B per voxel: each voxel with its +x, +y, +x+y neighbours)
-                                       and fetch the 8 corners of a strictly interior cell with two 16-byte loads
-                                       instead of four 8-byte ones.  Bit-identical results.  Needs a 16-byte aligned
-                                       workspace of drrt_workspace_bytes_grid() bytes.  Pays off when the call does
-                                       well over ~6 ray-steps per voxel (the copy costs 20 B of traffic per voxel) */
-#define DRRT_FLAG_QUAD_REUSE  128u  /* with QUAD_GRID: the workspace still holds the quad copy built by the previous
+#define DRRT_FLAG_PAIR_GRID    64u  /* trace / trace_pln / trace_sdf / backtrace*: build the "pair copy" of the grid in the
+                                       workspace (8 B per voxel: each voxel interleaved with its +y neighbour) and
+                                       fetch the 8 corners of a strictly interior cell with two 16-byte loads instead
+                                       of four 8-byte ones -- the march is bound by the number of gather instructions
+                                       (DESIGN.md 5.1).  Bit-identical results.  Needs a 16-byte aligned workspace of
+                                       drrt_workspace_bytes_grid() bytes.  Pays off when the call does well over ~4
+                                       ray-steps per voxel (the copy costs 12 B of traffic per voxel)              */
+#define DRRT_FLAG_PAIR_REUSE  128u  /* with PAIR_GRID: the workspace still holds the pair copy built by the previous
                                        call (same rif contents, same n, same flags & SORT_RAYS, same workspace) --
                                        e.g. the adjoint paired with its forward: skip the rebuild                  */
+#define DRRT_FLAG_QUAD_GRID  DRRT_FLAG_PAIR_GRID    /* round-1 names (the copy then held an (x,y) quad per voxel)   */
+#define DRRT_FLAG_QUAD_REUSE DRRT_FLAG_PAIR_REUSE
 #define DRRT_FLAG_TAP_REUSE_MASK 0x30000u /* trace / trace_pln / trace_sdf (A-B measurement; results are bit-identical):   */
 #define DRRT_FLAG_TAP_REUSE_OFF  0x10000u /*   gather all 8 taps at every step                                              */
 #define DRRT_FLAG_TAP_REUSE_FACE 0x20000u /*   also keep the shared face across a y- or z-move (2 pair loads instead of 4)  */
@@ -112,8 +115,8 @@ typedef struct drrt_stats {
 
 /* Bytes of device scratch a call over `n` rays may need (0 when flags need none). */
 DRRT_API size_t drrt_workspace_bytes(size_t n, unsigned flags);
-/* Same, for a call on a grid of `nvox` voxels: adds the quad copy when DRRT_FLAG_QUAD_GRID is set and the
- * 512-byte counter block.  Layout: [sort buffers | trace_target state][quad copy][counters].          */
+/* Same, for a call on a grid of `nvox` voxels: adds the pair copy when DRRT_FLAG_PAIR_GRID is set and the
+ * 512-byte counter block.  Layout: [sort buffers | trace_target state][pair copy][counters].          */
 DRRT_API size_t drrt_workspace_bytes_grid(size_t n, long long nvox, unsigned flags);
 
 /* Message of the last error on this thread ("" if none). */
@@ -341,7 +344,7 @@ DRRT_API int drrt_gen_cone_rays_f32(const float* u, const float* view_rot, int n
 #define DRRT_PROF_BACKTRACE  2   /* adjoint march kernel                 */
 #define DRRT_PROF_SORT       3   /* entry-voxel keys + radix sort        */
 #define DRRT_PROF_ZERO       4   /* zero-fill of the gradient grid       */
-#define DRRT_PROF_QUAD       5   /* build of the quad copy of the grid   */
+#define DRRT_PROF_QUAD       5   /* build of the pair copy of the grid   */
 DRRT_API int  drrt_profile_begin(int capacity);
 DRRT_API int  drrt_profile_collect(int* kernel_ids, float* ms, int max_out);
 DRRT_API void drrt_profile_end(void);
