@@ -30,6 +30,7 @@ FLAG_NO_PIPELINE = 0x40000
 FLAG_LEGACY_ADJOINT = 0x80000
 FLAG_LEGACY_FORWARD = 0x100000
 FLAG_Q16_POS_ONLY = 0x200000
+ADAM_MASK_BOUNDARY, ADAM_CLAMP_MIN = 1, 2
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "drrt_sensor_far_splat_f32": (_i, [_sz, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _u, _vp]),
     "drrt_sensor_far_splat_bwd_f32": (_i, [_sz, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "drrt_upres_volume_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "drrt_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _d, _u, _vp]),
     "drrt_gen_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "drrt_gen_rays_f32": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "drrt_gen_cone_rays_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _vp, _d, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -363,3 +363,69 @@ extern "C" int drrt_upres_volume_f32(const float* src, const int src_shape[3], f
   hipError_t le = hipGetLastError();
   return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
 }
+
+// =============================================================================================
+// one optimiser iteration's tail (SURVEY.md 8.8 "next" row 3): boundary-gradient mask + Adam + clamp
+//
+// Reference: core/optimizer.py:57-69 -- `n.grad[mask] = 0` (mask = the outermost voxel layer, :54-55),
+// `opto.step()` with torch.optim.Adam, `n.clamp_(min=1)`.  In torch that is a boolean-mask index_put (a nonzero()
+// with a host sync), ~10 element-wise launches and three extra passes over the volume and its two moments; here it
+// is ONE pass: 16 B read + 12 B written per voxel.  The update is torch's Adam (torch/optim/adam.py
+// _single_tensor_adam, amsgrad = maximize = False), bias corrections computed by the caller in double:
+//   g     = grad (0 on the boundary layer; written back there like the reference's in-place mask) + weight_decay * p
+//   m    += (g - m) * (1 - beta1)                      (exp_avg.lerp_)
+//   v     = beta2 * v + (1 - beta2) * g * g
+//   p    -= step_size * m / (sqrt(v) / sqrt(bias_correction2) + eps),   step_size = lr / bias_correction1
+//   p     = p < clamp_min ? clamp_min : p              (NaN stays NaN, like clamp_)
+// =============================================================================================
+namespace drrt {
+
+struct AdamArgs {
+  float* p; float* g; float* m; float* v;
+  size_t n; int s0, s1, s2;             // torch shape (z, y, x): x fastest
+  float step_size, bc2_sqrt, beta2, omb1, omb2, eps, weight_decay, clamp_min;   // omb = 1 - beta, rounded from double like torch's scalars
+  int mask_boundary, clamp;
+};
+
+__global__ void __launch_bounds__(256) k_adam_masked(AdamArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  float g = a.g[i];
+  if (a.mask_boundary) {
+    const int x = (int)(i % (size_t)a.s2), y = (int)((i / (size_t)a.s2) % (size_t)a.s1), z = (int)(i / ((size_t)a.s2 * a.s1));
+    if ((x == 0) | (x == a.s2 - 1) | (y == 0) | (y == a.s1 - 1) | (z == 0) | (z == a.s0 - 1)) { g = 0.f; a.g[i] = 0.f; }
+  }
+  float p = a.p[i], m = a.m[i], v = a.v[i];
+  if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);
+  m = fmaf(g - m, a.omb1, m);
+  v = fmaf(a.omb2, g * g, a.beta2 * v);
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  p = fmaf(-a.step_size, m / denom, p);
+  if (a.clamp) p = (p < a.clamp_min) ? a.clamp_min : p;
+  a.p[i] = p; a.m[i] = m; a.v[i] = v;
+}
+
+}  // namespace drrt
+
+extern "C" int drrt_adam_step_f32(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const int shape[3],
+                                  double step, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                  double clamp_min, unsigned flags, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !shape) return sensor_fail(DRRT_ERR_ARG, "null pointer");
+  for (int k = 0; k < 3; ++k) if (shape[k] < 1) return sensor_fail(DRRT_ERR_ARG, "bad shape");
+  if (!(step >= 1.0)) return sensor_fail(DRRT_ERR_ARG, "step must be >= 1 (the value AFTER the increment, like torch's)");
+  drrt::AdamArgs a{};
+  a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq;
+  a.s0 = shape[0]; a.s1 = shape[1]; a.s2 = shape[2];
+  a.n = (size_t)shape[0] * shape[1] * shape[2];
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);       // torch/optim/adam.py
+  a.step_size = (float)(lr / bc1); a.bc2_sqrt = (float)sqrt(bc2);
+  a.beta2 = (float)beta2; a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+  a.eps = (float)eps; a.weight_decay = (float)weight_decay;
+  a.clamp_min = (float)clamp_min;
+  a.mask_boundary = (flags & DRRT_ADAM_MASK_BOUNDARY) ? 1 : 0;
+  a.clamp = (flags & DRRT_ADAM_CLAMP_MIN) ? 1 : 0;
+  hipLaunchKernelGGL(drrt::k_adam_masked, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+

@@ -54,8 +54,10 @@ N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMDs
 CLK_HZ = 2.4e9                 # nominal shader clock (the chip may hold less under load; stated, not measured)
 VALU_CYCLES = 4.0              # a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU counts
                                # exactly one quad-cycle per instruction on these kernels; tools/valu_bench.hip: 3.9)
-TA_LANES_PER_CLK_CU = 3.4      # texture-addresser rate of a pair gather, lanes per clock per CU (tools/gather_bench.hip:
-                               # 2.1e12 lane-addresses/s chip-wide with nothing else in the loop)
+TA_CYCLES_PER_GATHER = 30.0    # a divergent 64-lane gather instruction occupies its CU's texture addresser for ~30-37 cycles,
+                               # with ONE active lane as with 64 (tools/chain_bench.hip: 15 ns per instruction per CU at 8
+                               # waves per SIMD); the low end is used -- an estimate, the instruction COUNT is from the PMC
+N_CU = 256
 
 
 def parse_args(argv=None):
@@ -209,29 +211,34 @@ def pmc_kernel(pmc, *prefixes):
     return None
 
 
-def physical_bound(pk, ms, lane_addresses):
+def physical_bound(pk, ms):
     """Which on-chip unit bounds a march kernel, from the PMC summary `pk` of the same command and the live kernel
-    time `ms`: VALU issue (instructions x 4 cycles per SIMD) vs the texture addresser (gather lane-addresses)."""
+    time `ms`: VALU issue (instructions x 4 cycles per SIMD) vs the texture addresser (gather INSTRUCTIONS x ~30 cycles
+    per CU -- its cost does not depend on how many lanes are active)."""
     out = {}
-    if ms != ms or ms <= 0:
+    if ms != ms or ms <= 0 or not pk:
         return out
     cyc = ms * 1e-3 * CLK_HZ
-    ta = lane_addresses / (TA_LANES_PER_CLK_CU * 256 * cyc)
-    out["ta_gather_frac_est"] = ta
-    if pk and "SQ_INSTS_VALU" in pk:
+    valu = ta = None
+    if "SQ_INSTS_VALU" in pk:
         valu = pk["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMD * cyc)
         out["valu_issue_frac"] = valu
         out["valu_insts_per_launch_pmc"] = pk["SQ_INSTS_VALU"]
-        if valu >= ta:
-            out["physical_bound"], out["physical_frac"] = "valu_issue", valu
-        else:
-            out["physical_bound"], out["physical_frac"] = "texture_addresser_gather", ta
+    if "SQ_INSTS_VMEM_RD" in pk:
+        ta = pk["SQ_INSTS_VMEM_RD"] * TA_CYCLES_PER_GATHER / (N_CU * cyc)
+        out["ta_gather_frac_est"] = ta
+        out["gather_insts_per_launch_pmc"] = pk["SQ_INSTS_VMEM_RD"]
+    if valu is None and ta is None:
+        return out
+    if ta is None or (valu is not None and valu >= ta):
+        out["physical_bound"], out["physical_frac"] = "valu_issue", valu
     else:
-        out["physical_bound"], out["physical_frac"] = "texture_addresser_gather", ta
+        out["physical_bound"], out["physical_frac"] = "texture_addresser_gather_instructions", ta
     out["physical_note"] = (f"taps are served by L1/L2/Infinity Cache (the 64 MiB grid is cache-resident), so HBM is not the "
                             f"physical limiter; fractions assume the nominal {CLK_HZ / 1e9:.1f} GHz clock, VALU = "
-                            f"{VALU_CYCLES:.0f} cycles per wave64 instruction per SIMD, gather = {TA_LANES_PER_CLK_CU} "
-                            f"lane-addresses per clock per CU")
+                            f"{VALU_CYCLES:.0f} cycles per wave64 instruction per SIMD (tools/valu_bench.hip: 3.9-4.8), a "
+                            f"gather instruction = {TA_CYCLES_PER_GATHER:.0f} cycles of its CU's texture addresser "
+                            f"(tools/chain_bench.hip: 30-37); instruction counts from the committed PMC summary")
     return out
 
 
@@ -445,17 +452,14 @@ def run_rank(args) -> int:
                 "traffic_source": src_note, "pmc_source": pmc_src,
                 "hbm_measured_gbps": (tr_adj / (ms_adj * 1e-3) / 1e9) if tr_adj else None,
                 "algorithmic_bytes_per_ray_step": B_ADJ, "ray_steps_per_launch": adj_steps, "avg_kernel_ms": ms_adj}
-        # gather lane-addresses: 4 pair loads per lane-step in which the ray ENTERS a new cell; with ds = h/2 that is
-        # ~0.6 of the lane-steps (every second step along the main axis + the transverse crossings) -- an estimate
-        GATHER_FRACTION = 0.6
-        roof.update(physical_bound(pk_adj, ms_adj, 4.0 * GATHER_FRACTION * adj_steps))
+        roof.update(physical_bound(pk_adj, ms_adj))
         roof_f = {"bound": "hbm", "kernel": "forward march (k_trace_flat)", "achieved": ach_fwd,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_fwd / HBM_PEAK_GBS, "traffic": tr_fwd,
                   "traffic_source": src_note, "pmc_source": pmc_src,
                   "hbm_measured_gbps": (tr_fwd / (ms_fwd * 1e-3) / 1e9) if tr_fwd else None,
                   "algorithmic_bytes_per_ray_step": B_FWD, "ray_steps_per_launch": fwd_steps, "avg_kernel_ms": ms_fwd,
                   "note": "frac can exceed 1: SURVEY 8.6 counts every tap as an HBM read, but the taps are cache-served"}
-        roof_f.update(physical_bound(pk_fwd, ms_fwd, 4.0 * GATHER_FRACTION * fwd_steps))
+        roof_f.update(physical_bound(pk_fwd, ms_fwd))
         out = {
             "metric": "ray-steps/sec (fwd+adjoint), 256^3 RIF grid, 1M rays x 512 steps",
             "value": m["fwd_total"] * args.steps / m["elapsed"],

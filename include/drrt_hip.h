@@ -302,6 +302,18 @@ DRRT_API int drrt_sensor_far_splat_bwd_f32(size_t n, const float* v, const float
 DRRT_API int drrt_upres_volume_f32(const float* src, const int src_shape[3], float* dst, const int dst_shape[3],
                           void* stream);
 
+/* core/optimizer.py:57-69, the tail of one multires_opt iteration in ONE pass over the volume: the boundary-gradient
+ * mask `n.grad[mask] = 0` (mask = outermost voxel layer, :54-55), `opto.step()` of torch.optim.Adam (amsgrad = maximize
+ * = False; formula of torch/optim/adam.py) and `n.clamp_(min=1)`.  All four arrays are DEVICE fp32 arrays of
+ * shape[0]*shape[1]*shape[2] elements (torch order, last axis fastest), updated in place (grad: zeroed on the boundary
+ * layer, like the reference).  `step` is the step count AFTER this update's increment (1 for the first call); lr, betas,
+ * eps, weight_decay are the param group's values.                                                                  */
+#define DRRT_ADAM_MASK_BOUNDARY 1u  /* treat the gradient of the outermost voxel layer as 0 (and zero it in `grad`) */
+#define DRRT_ADAM_CLAMP_MIN     2u  /* clamp the updated parameter from below at clamp_min                          */
+DRRT_API int drrt_adam_step_f32(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const int shape[3],
+                       double step, double lr, double beta1, double beta2, double eps, double weight_decay,
+                       double clamp_min, unsigned flags, void* stream);
+
 /* ---- ray generation (SURVEY.md 8.8 "next" row 2) ---------------------------------------------------
  * kind 0: core/source.py:54-69 plane_source3_rand + :275-293 rotate_pts_to_source;
  * kind 1: :72-104 point_source3_rand -- for n_views views in one call (what :352-357 rand_rays_in_sphere,
