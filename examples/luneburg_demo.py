@@ -2,7 +2,7 @@
 """End-to-end use of the drop-in API: design a gradient-index lens that focuses a plane wave onto
 the far face of the volume, coarse-to-fine, with Adam -- the flow of the reference's
 core/luneburg_opt.py (`run_opt` :33-128) and core/optimizer.py (`multires_opt` :44-84), written
-against this package's `tracer.BackTracerC` / `sensor.trace_rays_to_plane` (same call shapes:
+against this package's `optimizer.multires_opt` / `tracer.BackTracerC` / `sensor.trace_rays_to_plane` (same call shapes:
 `trace_fun(nt, x, v, h, ds)`, core/luneburg_opt.py:85-89).
 
     python examples/luneburg_demo.py [--res 9 17 33] [--iters 40] [--rays 64]
@@ -12,14 +12,13 @@ from __future__ import annotations
 import argparse
 import os
 import sys
+import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
 import torch
-import torch.nn.functional as F
-
-from adjointnonlinearraytracing_amd import sensor, tracer
+from adjointnonlinearraytracing_amd import optimizer, sensor, tracer
 
 
 def plane_rays(pixels: int, span: float, device, gen) -> tuple:
@@ -37,44 +36,33 @@ def plane_rays(pixels: int, span: float, device, gen) -> tuple:
     return pos.to(device), vel.to(device)
 
 
-def upres(n: torch.Tensor, res: int) -> torch.Tensor:
-    """Trilinear up-sampling of the volume between levels (core/optimizer.py:7-10 upres_scene)."""
-    return F.interpolate(n[None, None], size=(res,) * 3, mode="trilinear", align_corners=True)[0, 0].contiguous()
-
-
-def run(res_list=(9, 17, 33), iters=40, pixels=64, span=20.0, lr=1e-3, seed=0, verbose=True):
+def run(res_list=(9, 17, 33), iters=40, pixels=64, span=20.0, lr=1e-3, seed=0, verbose=True, fused=True):
     # vol_span = 20, lr = 0.001: the reference's run_default_opt (core/luneburg_opt.py:13-30)
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(seed)
     h_fine = span / (res_list[-1] - 1)
     ds = h_fine / 2                                            # ds fixed across levels (:48-49)
     focus = torch.tensor([[span / 2, span, span / 2]], device=dev)
-    n = torch.ones((res_list[0],) * 3, device=dev)
-    history = []
-    for level, res in enumerate(res_list):
-        if level:
-            n = upres(n.detach(), res)
-        n = n.clone().requires_grad_(True)
-        opt = torch.optim.Adam([n], lr=lr)
-        h = span / np.maximum(res - 1, 1)                      # numpy float64 scalar, as in :87
-        for it in range(iters):
-            x, v = plane_rays(pixels, span, dev, gen)
-            opt.zero_grad()
-            xt, vt = tracer.BackTracerC.apply(n, x, v, h, ds)
-            sp = focus.expand_as(xt)
-            sn = torch.tensor([[0.0, 1.0, 0.0]], device=dev).expand_as(xt)
-            xp, _ = sensor.trace_rays_to_plane((xt, vt), (sp, sn))
-            loss = torch.sum((xp - sp) ** 2) / x.shape[0] / span          # near_loss, :100-102
-            loss.backward()
-            with torch.no_grad():                              # boundary voxels stay fixed (optimizer.py:63)
-                n.grad[0, :, :] = 0; n.grad[-1, :, :] = 0; n.grad[:, 0, :] = 0
-                n.grad[:, -1, :] = 0; n.grad[:, :, 0] = 0; n.grad[:, :, -1] = 0
-            opt.step()
-            with torch.no_grad():
-                n.clamp_(min=1.0)                              # optimizer.py:68
-            history.append(float(loss.detach()))
-            if verbose and (it % 10 == 0 or it == iters - 1):
-                print(f"level {res:3d}^3  iter {it:3d}  loss {float(loss.detach()):.5f}")
+
+    def trace_loss(n):                                         # the `func` of multires_opt (core/luneburg_opt.py:91-104)
+        h = span / np.maximum(n.shape[0] - 1, 1)               # numpy float64 scalar, as in :87
+        x, v = plane_rays(pixels, span, dev, gen)
+        xt, vt = tracer.BackTracerC.apply(n, x, v, h, ds)
+        sp = focus.expand_as(xt)
+        sn = torch.tensor([[0.0, 1.0, 0.0]], device=dev).expand_as(xt)
+        xp, _ = sensor.trace_rays_to_plane((xt, vt), (sp, sn))
+        return torch.sum((xp - sp) ** 2) / x.shape[0] / span   # near_loss, :100-102
+
+    def log(it, n):
+        if verbose and it % 10 == 0:
+            print(f"iter {it:4d}  {n.shape[0]:3d}^3")
+
+    eta = torch.ones((res_list[0],) * 3, device=dev)
+    with tempfile.TemporaryDirectory() as tmp:
+        # core/optimizer.py:44-84: iters * (level + 1) Adam steps per level, boundary gradients masked, values clamped
+        # at 1, volume and Adam moments up-sampled between levels, one checkpoint per level
+        n, history = optimizer.multires_opt(trace_loss, eta, iters, list(res_list), log_func=log, lr=lr,
+                                            statename=os.path.join(tmp, "state.pt"), fused=fused)
     return n.detach(), history
 
 
