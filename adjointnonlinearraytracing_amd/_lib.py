@@ -30,6 +30,7 @@ FLAG_NO_PIPELINE = 0x40000
 FLAG_LEGACY_ADJOINT = 0x80000
 FLAG_LEGACY_FORWARD = 0x100000
 FLAG_Q16_POS_ONLY = 0x200000
+FLAG_STATIC_WINDOW = 0x400000
 ADAM_MASK_BOUNDARY, ADAM_CLAMP_MIN = 1, 2
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
@@ -72,6 +73,8 @@ SIGNATURES = {
     "drrt_sensor_splat_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "drrt_sensor_far_splat_f32": (_i, [_sz, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _u, _vp]),
     "drrt_sensor_far_splat_bwd_f32": (_i, [_sz, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "drrt_rays_to_plane_f32": (_i, [_sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "drrt_rays_to_plane_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "drrt_upres_volume_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "drrt_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _d, _u, _vp]),
     "drrt_gen_workspace_bytes": (_sz, [_i, _i, _i, _i]),

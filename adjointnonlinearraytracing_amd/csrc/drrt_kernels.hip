@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 
@@ -565,6 +566,7 @@ struct BackArgs {
   int max_steps;
   unsigned long long* dbg;     // nullable: [0] window flushes, [1] taps via LDS, [2] taps via global fallback
   int experiment;              // development ablations (0 = product behaviour)
+  unsigned* select;            // nullable (k_backtrace_flat): [0] waves a fitted window would help, [1] waves classified
 };
 
 template <int MODE>
@@ -1006,6 +1008,79 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
 // 5.41-5.50 ms for k_backtrace_win<0> with the pipelined loop and 5.45 ms without); backtrace_sdf, the quad-grid option
 // and DRRT_FLAG_LEGACY_ADJOINT keep k_backtrace_win.
 // ---------------------------------------------------------------------------------------------
+// ---- window of k_backtrace_flat: dimensions chosen when it is anchored -------------------------------------------
+// A wave's 64 rays usually fit the default 9^3 window, but not always: the locality sort forms Z-order tiles whose
+// aspect can reach 2:1, and the rays of a view that is oblique to the grid start the adjoint on an oblique exit face,
+// i.e. staggered along their direction (measured: a 45-degree plane view with 4 rays per voxel column had 27 % of its
+// ray-steps outside a 9^3 window and ran 4x slower per ray-step than the axis-aligned view).  So when lanes still miss
+// the default window right after it was re-anchored, the wave switches to windows fitted to the bounding box of its
+// rays' cells, within the same LDS capacity.  Everything here is wave-uniform (SGPRs).
+constexpr int kWinCap = 1000;      // slots per wave (8000 B): 5 blocks of 4 waves per CU, what the VGPR count allows anyway
+struct WinDyn {
+  int ox, oy, oz;                  // corner 000 of the window, in voxels (far away = nothing is inside)
+  int dx, dy, dz;                  // slots per axis; a cell (lx, ly, lz) needs slots lx..lx+1 etc., so dim - 1 cells fit
+  int sy, sz;                      // LDS strides of y and z in slots: sy = dx + 1 (pad), sz = sy * dy
+  int rpp;                         // flush: rows per pass = 64 / dx
+  float inv_dx, inv_dy;            // flush: 1/dx, 1/dy (lane -> row, row -> (ly, lz))
+};
+__device__ __forceinline__ void win_set_dims(WinDyn& W, int dx, int dy, int dz) {
+  dx = __builtin_amdgcn_readfirstlane(dx); dy = __builtin_amdgcn_readfirstlane(dy); dz = __builtin_amdgcn_readfirstlane(dz);
+  W.dx = dx; W.dy = dy; W.dz = dz; W.sy = dx + 1; W.sz = (dx + 1) * dy;
+  W.rpp = __builtin_amdgcn_readfirstlane((int)(64.0f / (float)dx));
+  W.inv_dx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / (float)dx)));
+  W.inv_dy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / (float)dy)));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ int win_index_dyn(const WinDyn& W, int cx, int cy, int cz) {
+  const int lx = cx - W.ox, ly = cy - W.oy, lz = cz - W.oz;
+  const bool in = ((unsigned)lx < (unsigned)(W.dx - 1)) & ((unsigned)ly < (unsigned)(W.dy - 1)) &
+                  ((unsigned)lz < (unsigned)(W.dz - 1));
+  // v_mad_u32_u24 by hand (lx, ly, lz are small and non-negative whenever the result is used)
+  int r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(ly), "s"(W.sy), "v"(lx));
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(lz), "s"(W.sz), "v"(r));
+  return in ? r : -1;
+}
+// Flush the window into the grid and leave it zeroed (all 64 lanes).  Rows (the dx slots of one (ly, lz)) are contiguous
+// in LDS at pitch sy, so the flush walks them linearly, rpp = 64 / dx rows per pass (lane -> row lane / dx, slot
+// lane % dx), four passes per batch: four LDS exchanges are in flight before the first result is used.
+__device__ __forceinline__ void win_flush_dyn(win_t* win, const WinDyn& W, float* __restrict__ grad, const Vol& V,
+                                              int lane, bool no_global) {
+  wave_lds_fence();
+  const int rows = W.dy * W.dz;
+  const int rsub = (int)(((float)lane + 0.5f) * W.inv_dx), lx = lane - rsub * W.dx;
+  const bool lane_ok = rsub < W.rpp;
+  const unsigned g0 = (unsigned)W.oz * (unsigned)V.sz + (unsigned)W.oy * (unsigned)V.sy + (unsigned)(W.ox + lx);
+  constexpr int kBatch = 4;
+#pragma unroll 1
+  for (int r0 = 0; r0 < rows; r0 += kBatch * W.rpp) {
+    win_t v[kBatch];
+    unsigned g[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const int r = r0 + b * W.rpp + rsub;                                   // row index = lz * dy + ly
+      const int lz = (int)(((float)r + 0.5f) * W.inv_dy), ly = r - lz * W.dy;
+      v[b] = (win_t)0;
+      g[b] = g0 + (unsigned)lz * (unsigned)V.sz + (unsigned)ly * (unsigned)V.sy;
+      // ds_wrxchg_rtn_b64: read the accumulated value and reset the slot in one LDS op
+      if (lane_ok & (r < rows)) v[b] = __hip_atomic_exchange(win + r * W.sy + lx, (win_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b)
+      if (v[b] != (win_t)0 && !no_global) atomic_add_f32(grad + g[b], (float)v[b]);
+  }
+  wave_lds_fence();
+}
+
 __device__ __forceinline__ int win_index(int wox, int woy, int woz, int cx, int cy, int cz) {
   const int lx = cx - wox, ly = cy - woy, lz = cz - woz;
   const bool in = ((unsigned)lx < (unsigned)(kWinX - 1)) & ((unsigned)ly < (unsigned)(kWinY - 1)) &
@@ -1019,7 +1094,7 @@ __device__ __forceinline__ int win_index(int wox, int woy, int woz, int cx, int 
 }
 
 // all 8 accumulated corners of the regular cell `base` (window slot lidx, or -1: straight to the grid)
-__device__ __forceinline__ bool flat_emit8(win_t* win, float* grad, int sy, int sz, int lidx, int base,
+__device__ __forceinline__ bool flat_emit8(win_t* win, int wsy, int wsz, float* grad, int sy, int sz, int lidx, int base,
                                            f2 p00, f2 p10, f2 p01, f2 p11) {
   if (lidx >= 0) {
     // quad pre-reduction: when the 4 lanes of a quad hand over the same cell, one lane adds the quad's sums
@@ -1029,10 +1104,10 @@ __device__ __forceinline__ bool flat_emit8(win_t* win, float* grad, int sy, int 
     for (int k = 0; k < 8; ++k) { const float qs = quad_sum(v[k]); v[k] = same ? qs : v[k]; }
     if (!same || (threadIdx.x & 3u) == 0u) {
       win_t* q = win + lidx;
-      atomicAdd(q, (win_t)v[0]);                     atomicAdd(q + 1, (win_t)v[1]);
-      atomicAdd(q + kWinSY, (win_t)v[2]);            atomicAdd(q + kWinSY + 1, (win_t)v[3]);
-      atomicAdd(q + kWinSZ, (win_t)v[4]);            atomicAdd(q + kWinSZ + 1, (win_t)v[5]);
-      atomicAdd(q + kWinSZ + kWinSY, (win_t)v[6]);   atomicAdd(q + kWinSZ + kWinSY + 1, (win_t)v[7]);
+      atomicAdd(q, (win_t)v[0]);                 atomicAdd(q + 1, (win_t)v[1]);
+      atomicAdd(q + wsy, (win_t)v[2]);           atomicAdd(q + wsy + 1, (win_t)v[3]);
+      atomicAdd(q + wsz, (win_t)v[4]);           atomicAdd(q + wsz + 1, (win_t)v[5]);
+      atomicAdd(q + wsz + wsy, (win_t)v[6]);     atomicAdd(q + wsz + wsy + 1, (win_t)v[7]);
     }
     return true;
   }
@@ -1044,15 +1119,54 @@ __device__ __forceinline__ bool flat_emit8(win_t* win, float* grad, int sy, int 
   return false;
 }
 
+// How do the 64-ray bundles of this call sit at the start of the adjoint march?  One wave per bundle (the rays of 64
+// consecutive visit slots): bounding box of the rays' start cells -> [0] += 1 when the default window cannot hold it
+// but a fitted one can (WinDyn), [1] += 1 for every bundle looked at.  k_backtrace_flat<.., DYN> reads the two counters.
+constexpr unsigned kClassifyStride = 16;     // every 16th block of bundles is looked at (contended atomics are the cost)
+__global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
+  const Vol& V = a.vol;
+  const size_t t = (size_t)blockIdx.x * kClassifyStride * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  size_t i;
+  bool ok = false;
+  int cx = 0, cy = 0, cz = 0;
+  if (ray_index(a.perm, t, a.n, i)) {
+    const Ray3 p = ld3(a.xt, i, a.io_half, &a.vol, RAY_POS);
+    const Cell c = locate(V, p.x, p.y, p.z);
+    cx = c.ix; cy = c.iy; cz = c.iz; ok = true;
+  }
+  const int big = 1 << 28;
+  const int x0 = wave_min_i32(ok ? cx : big), x1 = wave_max_i32(ok ? cx : -big);
+  const int y0 = wave_min_i32(ok ? cy : big), y1 = wave_max_i32(ok ? cy : -big);
+  const int z0 = wave_min_i32(ok ? cz : big), z1 = wave_max_i32(ok ? cz : -big);
+  if (lane == 0 && x1 >= x0) {
+    const int ex = x1 - x0 + 2, ey = y1 - y0 + 2, ez = z1 - z0 + 2;           // slots per axis
+    const bool dflt = (ex <= kWinX - 2) & (ey <= kWinY - 2) & (ez <= kWinZ - 2);   // two slots of room for the placement
+    const bool fit = (ex <= 16) & ((ex + 1) * ey * ez <= kWinCap);
+    if (!dflt && fit) atomicAdd(&a.select[0], 1u);
+    atomicAdd(&a.select[1], 1u);
+  }
+}
+
 #ifndef DRRT_ADJ_WAVES
-#define DRRT_ADJ_WAVES 1
+#define DRRT_ADJ_WAVES 5     // 5 waves per SIMD: caps the kernel at 96 VGPRs (it sits right at that edge); LDS allows 5 blocks per CU too
 #endif
-template <bool ABL, bool PAIR>   // PAIR: gather from the pair copy of the grid (two 16-byte loads per cell, see gather_rows)
+// PAIR: gather from the pair copy of the grid (two 16-byte loads per cell, see gather_rows).
+// DYN : windows with run-time dimensions, fitted to the wave's rays when the default kWin^3 window cannot hold them
+//       (WinDyn); DYN = false is the kernel with compile-time window strides.  When the call has a visit order the host
+//       launches BOTH and each instance returns at once unless a.select picks it (k_bundle_classify decides on the
+//       device, from how the 64-ray bundles sit at their start, without a host round trip).
+template <bool ABL, bool PAIR, bool DYN>
 __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackArgs a) {
-  __shared__ win_t s_win[kWavesPerBlock][kWinFloats];
+  if (a.select != nullptr) {
+    const bool want_dyn = a.select[0] * 8u >= a.select[1] && a.select[0] != 0u;     // >= 1/8 of the waves would gain
+    if (want_dyn != DYN) return;
+  }
+  constexpr int kSlots = DYN ? kWinCap : kWinFloats;
+  __shared__ win_t s_win[kWavesPerBlock][kSlots];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   win_t* win = s_win[wid];
-  for (int k = lane; k < kWinFloats; k += kWave) win[k] = (win_t)0;
+  for (int k = lane; k < kSlots; k += kWave) win[k] = (win_t)0;
   wave_lds_fence();
 
   const Vol& V = a.vol;
@@ -1067,7 +1181,9 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
     adj_init(V, a.ds, gxv.x, gxv.y, gxv.z, gvv.x, gvv.y, gvv.z, s);
   }
   const int experiment = ABL ? a.experiment : 0;
-  int wox = -(1 << 28), woy = -(1 << 28), woz = -(1 << 28);   // window origin (wave-uniform); far away = nothing is inside
+  WinDyn W;                                                    // the wave's window (wave-uniform)
+  win_set_dims(W, kWinX, kWinY, kWinZ);
+  W.ox = W.oy = W.oz = -(1 << 28);                             // far away = nothing is inside
   // the cell the ray stands on, located IN PLACE: flat index and coordinates of corner 000, in-cell fractions, strictly
   // interior / regular (no clamped neighbour), window slot.  A boundary cell's clamp offsets are not carried: the
   // boundary branch at the top of the step re-derives them from the position (locate()).
@@ -1081,32 +1197,31 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
   bool miss = false;                                         // the cell just entered lies outside the window
   const TapRows R = tap_rows<PAIR>(V);                       // wave-uniform row pointers + ONE 32-bit byte offset per lane
   // step to the next sample (:420), locate its cell in place and issue its gather unless the lane holds those taps
-#define DRRT_FLAT_STEP_LOCATE()                                                                                        \
-  do {                                                                                                                 \
-    s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);                          \
-    const float fx_ = s.x * V.inv_h, fy_ = s.y * V.inv_h, fz_ = s.z * V.inv_h;                                         \
-    ix = cvt_floor_i32(fx_); iy = cvt_floor_i32(fy_); iz = cvt_floor_i32(fz_);                                         \
-    interior = (((unsigned)ix - 1u) < V.lx) & (((unsigned)iy - 1u) < V.ly) & (((unsigned)iz - 1u) < V.lz);             \
-    if (interior) {                                                                                                    \
-      /* v_fract == f - floor(f) bit for bit for the non-negative coordinates of an interior cell */                    \
-      wx = __builtin_amdgcn_fractf(fx_); wy = __builtin_amdgcn_fractf(fy_); wz = __builtin_amdgcn_fractf(fz_);         \
-      nbase = mad24(iz, V.sz, mad24(iy, V.sy, ix));                                                                    \
-      nregular = true;                                                                                                 \
-      if (nbase != tbase) {                                                                                            \
-        __builtin_assume(nbase >= 0 && nbase < (1 << 29));                                                             \
-        gather_rows<PAIR>(R, tap_offset<PAIR>(nbase), q0, q1);                                                         \
-        tbase = nbase;                                                                                                 \
-      }                                                                                                                \
-    } else {                                                                                                           \
-      const Cell cb_ = locate(V, s.x, s.y, s.z);                                                                       \
-      wx = cb_.wx; wy = cb_.wy; wz = cb_.wz; ix = cb_.ix; iy = cb_.iy; iz = cb_.iz; nbase = cb_.base;                   \
-      nregular = (cb_.ox == 1) & (cb_.oy == V.sy) & (cb_.oz == V.sz);                                                  \
-      tbase = -1;                                                                                                      \
-    }                                                                                                                  \
-  } while (0)
+  auto step_locate = [&](int& nbase, bool& nregular) {
+    s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);
+    const float fx = s.x * V.inv_h, fy = s.y * V.inv_h, fz = s.z * V.inv_h;
+    ix = cvt_floor_i32(fx); iy = cvt_floor_i32(fy); iz = cvt_floor_i32(fz);
+    interior = (((unsigned)ix - 1u) < V.lx) & (((unsigned)iy - 1u) < V.ly) & (((unsigned)iz - 1u) < V.lz);
+    if (interior) {
+      // v_fract == f - floor(f) bit for bit for the non-negative coordinates of an interior cell
+      wx = __builtin_amdgcn_fractf(fx); wy = __builtin_amdgcn_fractf(fy); wz = __builtin_amdgcn_fractf(fz);
+      nbase = mad24(iz, V.sz, mad24(iy, V.sy, ix));
+      nregular = true;
+      if (nbase != tbase) {
+        __builtin_assume(nbase >= 0 && nbase < (1 << 29));
+        gather_rows<PAIR>(R, tap_offset<PAIR>(nbase), q0, q1);
+        tbase = nbase;
+      }
+    } else {
+      const Cell cb = locate(V, s.x, s.y, s.z);
+      wx = cb.wx; wy = cb.wy; wz = cb.wz; ix = cb.ix; iy = cb.iy; iz = cb.iz; nbase = cb.base;
+      nregular = (cb.ox == 1) & (cb.oy == V.sy) & (cb.oz == V.sz);
+      tbase = -1;
+    }
+  };
   if (s.active) {
     int nbase; bool nregular;
-    DRRT_FLAT_STEP_LOCATE();                                 // first sample
+    step_locate(nbase, nregular);                            // first sample
     base = nbase; regular = nregular;
     miss = regular;                                          // no window yet
   }
@@ -1115,166 +1230,218 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
   unsigned steps = 0;
   unsigned n_flush = 0;
 
-  for (int it = 0; it < a.max_steps; ++it) {
-    if (!__any(s.active)) break;                                              // wave-uniform exit
-    // ---- (re-)anchor the window around the cells the rays stand on (wave-uniform branch) ----
-    const unsigned long long mm = __ballot(s.active & miss);
-    if (mm != 0ull && cooldown == 0) {
-      if (dirty) { win_flush(win, wox, woy, woz, a.grad, V, lane, experiment == 2); dirty = false; ++n_flush; }
-      const unsigned long long cm = __ballot(s.active & regular);
-      const int first = __ffsll((long long)cm) - 1, last = 63 - __clzll((long long)cm);
-      int ref = (first + last) >> 1;
-      if (!((cm >> ref) & 1ull)) ref = first;
-      const int rx = __shfl(ix, ref, kWave), ry = __shfl(iy, ref, kWave), rz = __shfl(iz, ref, kWave);
-      const float dx_ = -__shfl(s.vx, ref, kWave), dy_ = -__shfl(s.vy, ref, kWave), dz_ = -__shfl(s.vz, ref, kWave);
-      const float inv_dm = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f)));   // placement only
-      const float fx = 0.5f - 0.35f * (dx_ * inv_dm), fy = 0.5f - 0.35f * (dy_ * inv_dm), fz = 0.5f - 0.35f * (dz_ * inv_dm);
-      int ox = rx - (int)(fx * (float)(kWinX - 2));
-      int oy = ry - (int)(fy * (float)(kWinY - 2));
-      int oz = rz - (int)(fz * (float)(kWinZ - 2));
-      ox = max(0, min(ox, V.W - kWinX)); oy = max(0, min(oy, V.H - kWinY)); oz = max(0, min(oz, V.D - kWinZ));
-      wox = __builtin_amdgcn_readfirstlane(ox); woy = __builtin_amdgcn_readfirstlane(oy);
-      woz = __builtin_amdgcn_readfirstlane(oz);
-      lidx = regular ? win_index(wox, woy, woz, ix, iy, iz) : -1;             // every lane's cell, in the new window
-      miss = s.active & regular & (lidx < 0);
-      cooldown = (__ballot(miss) != 0ull) ? 4 : 0;                            // incoherent wave: do not thrash
-    } else if (cooldown > 0) {
-      --cooldown;
-    }
-    bool used_lds = false;
-    if (s.active) {
-      if (!interior) taps_set<PAIR>(fetch(V.data, locate(V, s.x, s.y, s.z)), q0, q1);   // boundary cell (clamped neighbours): fetched here, not ahead
-      Cell c;                                              // what adj_sample reads of the cell: fractions, interior
-      c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0;
-      c.wx = wx; c.wy = wy; c.wz = wz; c.interior = interior;
-      const float px = s.x, py = s.y, pz = s.z;            // position of this sample (the clamped splat re-locates it)
-      AdjSample m;
-      if (!adj_sample<0>(V, nullptr, a.ds, s, c, taps_of<PAIR>(q0, q1), m)) {
-        // the ray has ended (:426-428): it contributes nothing here; hand over what its cell has accumulated
-        if (regular && experiment != 1) used_lds = flat_emit8(win, a.grad, V.sy, V.sz, lidx, base, p00, p10, p01, p11);
-      } else {
-        ++steps;
+#define WSY (DYN ? W.sy : kWinSY)
+#define WSZ (DYN ? W.sz : kWinSZ)
+#define WIN_INDEX(cx, cy, cz) (DYN ? win_index_dyn(W, cx, cy, cz) : win_index(W.ox, W.oy, W.oz, cx, cy, cz))
+    for (int it = 0; it < a.max_steps; ++it) {
+      if (!__any(s.active)) break;                                              // wave-uniform exit
+      // ---- (re-)anchor the window around the cells the rays stand on (wave-uniform branch) ----
+      const unsigned long long mm = __ballot(s.active & miss);
+      if (mm != 0ull && cooldown == 0) {
+        if (dirty) {
+          if constexpr (DYN) win_flush_dyn(win, W, a.grad, V, lane, experiment == 2);
+          else win_flush(win, W.ox, W.oy, W.oz, a.grad, V, lane, experiment == 2);
+          dirty = false; ++n_flush;
+        }
+        const bool ok = s.active & regular;
+        const unsigned long long cm = __ballot(ok);
+        const int first = __ffsll((long long)cm) - 1, last = 63 - __clzll((long long)cm);
+        int ref = (first + last) >> 1;
+        if (!((cm >> ref) & 1ull)) ref = first;
+        const int rx = __shfl(ix, ref, kWave), ry = __shfl(iy, ref, kWave), rz = __shfl(iz, ref, kWave);
+        // backward direction of travel of the reference lane
+        const float dx_ = -__shfl(s.vx, ref, kWave), dy_ = -__shfl(s.vy, ref, kWave), dz_ = -__shfl(s.vz, ref, kWave);
+        const float inv_dm = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f)));   // placement only
         {
-          // first half of adj_contrib: the 8 splat weights (they need the in-cell fractions of THIS cell)
-          const float dn = dot3(s.mx, s.my, s.mz, m.gx, m.gy, m.gz);                            // :430
-          const float nds = (m.n * a.ds) * a.grad_scale;
-          if (regular) {
-            const CornerPairs cp = splat_weights_pk(wx, wy, wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);   // :431-432
-            p00 += cp.c00; p10 += cp.c10; p01 += cp.c01; p11 += cp.c11;
-          } else if (experiment != 2 && experiment != 1) {
-            // clamped boundary cell: taps coincide; straight to the grid
-            const Cell cb = locate(V, px, py, pz);
-            const Corners w = splat_weights(cb.wx, cb.wy, cb.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);
-            float* g = a.grad + cb.base;
-            atomic_add_f32(g, w.c000);                     atomic_add_f32(g + cb.ox, w.c100);
-            atomic_add_f32(g + cb.oy, w.c010);             atomic_add_f32(g + cb.oy + cb.ox, w.c110);
-            atomic_add_f32(g + cb.oz, w.c001);             atomic_add_f32(g + cb.oz + cb.ox, w.c101);
-            atomic_add_f32(g + cb.oz + cb.oy, w.c011);     atomic_add_f32(g + cb.oz + cb.oy + cb.ox, w.c111);
-          }
-          // step to the next sample and issue its gather (it + 1 == max_steps: located and fetched, never used)
-          const int old_base = base, old_lidx = lidx;
-          const bool old_regular = regular;
-          int nbase; bool nregular;
-          DRRT_FLAT_STEP_LOCATE();
-          // second half of adj_contrib: lambda / mu (:434-435)
-          const float hxy = m.hxy * V.inv_h2, hxz = m.hxz * V.inv_h2, hyz = m.hyz * V.inv_h2;
-          const float hmx = fmaf(hxz, s.mz, hxy * s.my);
-          const float hmy = fmaf(hyz, s.mz, hxy * s.mx);
-          const float hmz = fmaf(hyz, s.my, hxz * s.mx);
-          s.lx = fmaf(a.ds, fmaf(dn, m.gx, m.n * hmx), s.lx);
-          s.ly = fmaf(a.ds, fmaf(dn, m.gy, m.n * hmy), s.ly);
-          s.lz = fmaf(a.ds, fmaf(dn, m.gz, m.n * hmz), s.lz);
-          s.mx = fmaf(a.ds, s.lx, s.mx); s.my = fmaf(a.ds, s.ly, s.my); s.mz = fmaf(a.ds, s.lz, s.mz);
-          // ---- the ray leaves its cell ----
-          if (nbase != old_base || !interior) {
-            base = nbase; regular = nregular;
-            const int d = nbase - old_base;
-            if (d != 0 || regular != old_regular) {
-              const bool ax = (d == 1) | (d == -1), ay = (d == V.sy) | (d == -V.sy), az = (d == V.sz) | (d == -V.sz);
-              if (old_regular) {
-                if (regular & (ax | ay | az) & (experiment != 1) & (experiment != 4)) {
-                  // one face crossed: emit the face left behind, carry the shared one
-                  const bool fwd = d > 0;
-                  // emitted corners e0..e3 and carried ones, in (p, q) in-face order; LDS / grid strides of p, q and of the axis
-                  float e0, e1, e2, e3;
-                  int lp, lq, la, gp, gq, ga;
-                  if (ay) {
-                    const f2 ea = fwd ? p00 : p10, eb = fwd ? p01 : p11;
-                    e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
-                    const f2 ka = fwd ? p10 : p00, kb = fwd ? p11 : p01;
-                    p00 = fwd ? ka : f2{0.f, 0.f}; p01 = fwd ? kb : f2{0.f, 0.f};
-                    p10 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
-                    lp = 1; lq = kWinSZ; la = kWinSY; gp = 1; gq = V.sz; ga = V.sy;
-                  } else if (az) {
-                    const f2 ea = fwd ? p00 : p01, eb = fwd ? p10 : p11;
-                    e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
-                    const f2 ka = fwd ? p01 : p00, kb = fwd ? p11 : p10;
-                    p00 = fwd ? ka : f2{0.f, 0.f}; p10 = fwd ? kb : f2{0.f, 0.f};
-                    p01 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
-                    lp = 1; lq = kWinSY; la = kWinSZ; gp = 1; gq = V.sy; ga = V.sz;
-                  } else {
-                    e0 = fwd ? p00.x : p00.y; e1 = fwd ? p10.x : p10.y; e2 = fwd ? p01.x : p01.y; e3 = fwd ? p11.x : p11.y;
-                    p00 = fwd ? f2{p00.y, 0.f} : f2{0.f, p00.x}; p10 = fwd ? f2{p10.y, 0.f} : f2{0.f, p10.x};
-                    p01 = fwd ? f2{p01.y, 0.f} : f2{0.f, p01.x}; p11 = fwd ? f2{p11.y, 0.f} : f2{0.f, p11.x};
-                    lp = kWinSY; lq = kWinSZ; la = 1; gp = V.sy; gq = V.sz; ga = 1;
-                  }
-                  if (old_lidx >= 0) {
-                    if (experiment != 3) {
-                      const int qi = old_lidx + (fwd ? 0 : la);
-                      // pair / quad pre-reduction (see shift_emit4): lanes of a quad that go to the same four slots
-                      const int key = qi | ((ay ? 1 : (az ? 2 : 0)) << 16);
-                      const int k1 = __builtin_amdgcn_update_dpp(-1, key, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-                      const int k2 = __builtin_amdgcn_update_dpp(-1, key, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-                      const int k3 = __builtin_amdgcn_update_dpp(-1, key, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
-                      const bool psame = k1 == key;
-                      const bool same = psame & (k2 == key) & (k3 == key);
-                      float q0 = e0, q1 = e1, q2 = e2, q3 = e3;
-                      q0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, false));
-                      q1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, false));
-                      q2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q2), 0xB1, 0xF, 0xF, false));
-                      q3 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q3), 0xB1, 0xF, 0xF, false));
-                      const float s0 = q0 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q0), 0x4E, 0xF, 0xF, false));
-                      const float s1 = q1 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1), 0x4E, 0xF, 0xF, false));
-                      const float s2 = q2 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q2), 0x4E, 0xF, 0xF, false));
-                      const float s3 = q3 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q3), 0x4E, 0xF, 0xF, false));
-                      const unsigned ql = threadIdx.x & 3u;
-                      const bool add = same ? ql == 0u : (psame ? (ql & 1u) == 0u : true);
-                      if (experiment == 6) {            // ablation: no pre-reduction, every lane adds its own values
-                        win_t* q = win + qi;
-                        atomicAdd(q, (win_t)e0); atomicAdd(q + lp, (win_t)e1); atomicAdd(q + lq, (win_t)e2); atomicAdd(q + lq + lp, (win_t)e3);
-                      } else if (add) {
-                        win_t* q = win + qi;
-                        atomicAdd(q, (win_t)(same ? s0 : (psame ? q0 : e0)));      atomicAdd(q + lp, (win_t)(same ? s1 : (psame ? q1 : e1)));
-                        atomicAdd(q + lq, (win_t)(same ? s2 : (psame ? q2 : e2))); atomicAdd(q + lq + lp, (win_t)(same ? s3 : (psame ? q3 : e3)));
-                      }
-                    }
-                    used_lds = experiment != 5;         // ablation 5: never flush (until the end)
-                  } else if (experiment != 2) {
-                    float* g = a.grad + old_base + (fwd ? 0 : ga);
-                    atomic_add_f32(g, e0); atomic_add_f32(g + gp, e1); atomic_add_f32(g + gq, e2); atomic_add_f32(g + gq + gp, e3);
-                  }
-                } else {
-                  // jump over more than one face, or into a clamped cell: hand over all eight
-                  if (experiment != 1) used_lds = flat_emit8(win, a.grad, V.sy, V.sz, old_lidx, old_base, p00, p10, p01, p11);
-                  p00 = p10 = p01 = p11 = f2{0.f, 0.f};
-                }
+          // default: a kWin^3 window around the median lane's cell, shifted towards the direction of travel
+          if constexpr (DYN) { if (W.dx != kWinX || W.dy != kWinY || W.dz != kWinZ) win_set_dims(W, kWinX, kWinY, kWinZ); }
+          const float fx = 0.5f - 0.35f * (dx_ * inv_dm), fy = 0.5f - 0.35f * (dy_ * inv_dm), fz = 0.5f - 0.35f * (dz_ * inv_dm);
+          int ox = rx - (int)(fx * (float)(kWinX - 2));
+          int oy = ry - (int)(fy * (float)(kWinY - 2));
+          int oz = rz - (int)(fz * (float)(kWinZ - 2));
+          ox = max(0, min(ox, V.W - kWinX)); oy = max(0, min(oy, V.H - kWinY)); oz = max(0, min(oz, V.D - kWinZ));
+          W.ox = __builtin_amdgcn_readfirstlane(ox); W.oy = __builtin_amdgcn_readfirstlane(oy);
+          W.oz = __builtin_amdgcn_readfirstlane(oz);
+          lidx = regular ? WIN_INDEX(ix, iy, iz) : -1;                          // every lane's cell, in the new window
+          miss = ok & (lidx < 0);
+        }
+        if (DYN && __ballot(miss) != 0ull) {
+          // The default window cannot hold this wave.  Would a window fitted to the bounding box of its rays' cells?
+          const int big = 1 << 28;
+          const int x0 = wave_min_i32(ok ? ix : big), x1 = wave_max_i32(ok ? ix : -big);
+          const int y0 = wave_min_i32(ok ? iy : big), y1 = wave_max_i32(ok ? iy : -big);
+          const int z0 = wave_min_i32(ok ? iz : big), z1 = wave_max_i32(ok ? iz : -big);
+          const int ex = x1 - x0 + 2, ey = y1 - y0 + 2, ez = z1 - z0 + 2;       // slots the cells need per axis
+          const bool fits = __builtin_amdgcn_readfirstlane((int)((ex <= 16) & ((ex + 1) * ey * ez <= kWinCap))) != 0;
+          if (fits) {
+            if constexpr (DYN) {
+              // room ahead of the rays: up to 3 slots along the direction of travel, as far as the capacity allows
+              int dx = min(ex + (int)(3.0f * fabsf(dx_) * inv_dm + 0.5f), 16);
+              int dy = ey + (int)(3.0f * fabsf(dy_) * inv_dm + 0.5f);
+              int dz = ez + (int)(3.0f * fabsf(dz_) * inv_dm + 0.5f);
+              dx = __builtin_amdgcn_readfirstlane(dx); dy = __builtin_amdgcn_readfirstlane(dy); dz = __builtin_amdgcn_readfirstlane(dz);
+  #pragma unroll 1
+              for (int guard = 0; guard < 16 && (dx + 1) * dy * dz > kWinCap; ++guard) {
+                if (dz > ez && dz - ez >= dy - ey && dz - ez >= dx - ex) --dz;      // give back the largest margin first
+                else if (dy > ey && dy - ey >= dx - ex) --dy;
+                else if (dx > ex) --dx;
               }
-              lidx = regular ? win_index(wox, woy, woz, ix, iy, iz) : -1;
-              miss = regular & (lidx < 0);
+              win_set_dims(W, dx, dy, dz);
+              // origin: the box's low corner, moved back by the spare slots when the rays travel towards lower indices
+              int ox = dx_ < 0.f ? x0 - (dx - ex) : x0, oy = dy_ < 0.f ? y0 - (dy - ey) : y0, oz = dz_ < 0.f ? z0 - (dz - ez) : z0;
+              ox = max(0, min(ox, V.W - dx)); oy = max(0, min(oy, V.H - dy)); oz = max(0, min(oz, V.D - dz));
+              W.ox = __builtin_amdgcn_readfirstlane(ox); W.oy = __builtin_amdgcn_readfirstlane(oy);
+              W.oz = __builtin_amdgcn_readfirstlane(oz);
+              lidx = regular ? WIN_INDEX(ix, iy, iz) : -1;
+              miss = ok & (lidx < 0);
+            }
+          }
+        }
+        cooldown = (__ballot(miss) != 0ull) ? 4 : 0;                            // incoherent wave: do not thrash
+      } else if (cooldown > 0) {
+        --cooldown;
+      }
+      bool used_lds = false;
+      if (s.active) {
+        if (!interior) taps_set<PAIR>(fetch(V.data, locate(V, s.x, s.y, s.z)), q0, q1);   // boundary cell (clamped neighbours): fetched here, not ahead
+        Cell c;                                              // what adj_sample reads of the cell: fractions, interior
+        c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0;
+        c.wx = wx; c.wy = wy; c.wz = wz; c.interior = interior;
+        const float px = s.x, py = s.y, pz = s.z;            // position of this sample (the clamped splat re-locates it)
+        AdjSample m;
+        if (!adj_sample<0>(V, nullptr, a.ds, s, c, taps_of<PAIR>(q0, q1), m)) {
+          // the ray has ended (:426-428): it contributes nothing here; hand over what its cell has accumulated
+          if (regular && experiment != 1) used_lds = flat_emit8(win, WSY, WSZ, a.grad, V.sy, V.sz, lidx, base, p00, p10, p01, p11);
+        } else {
+          ++steps;
+          {
+            // first half of adj_contrib: the 8 splat weights (they need the in-cell fractions of THIS cell)
+            const float dn = dot3(s.mx, s.my, s.mz, m.gx, m.gy, m.gz);                            // :430
+            const float nds = (m.n * a.ds) * a.grad_scale;
+            if (regular) {
+              const CornerPairs cp = splat_weights_pk(wx, wy, wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);   // :431-432
+              p00 += cp.c00; p10 += cp.c10; p01 += cp.c01; p11 += cp.c11;
+            } else if (experiment != 2 && experiment != 1) {
+              // clamped boundary cell: taps coincide; straight to the grid
+              const Cell cb = locate(V, px, py, pz);
+              const Corners w = splat_weights(cb.wx, cb.wy, cb.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);
+              float* g = a.grad + cb.base;
+              atomic_add_f32(g, w.c000);                     atomic_add_f32(g + cb.ox, w.c100);
+              atomic_add_f32(g + cb.oy, w.c010);             atomic_add_f32(g + cb.oy + cb.ox, w.c110);
+              atomic_add_f32(g + cb.oz, w.c001);             atomic_add_f32(g + cb.oz + cb.ox, w.c101);
+              atomic_add_f32(g + cb.oz + cb.oy, w.c011);     atomic_add_f32(g + cb.oz + cb.oy + cb.ox, w.c111);
+            }
+            // step to the next sample and issue its gather (it + 1 == max_steps: located and fetched, never used)
+            const int old_base = base, old_lidx = lidx;
+            const bool old_regular = regular;
+            int nbase; bool nregular;
+            step_locate(nbase, nregular);
+            // second half of adj_contrib: lambda / mu (:434-435)
+            const float hxy = m.hxy * V.inv_h2, hxz = m.hxz * V.inv_h2, hyz = m.hyz * V.inv_h2;
+            const float hmx = fmaf(hxz, s.mz, hxy * s.my);
+            const float hmy = fmaf(hyz, s.mz, hxy * s.mx);
+            const float hmz = fmaf(hyz, s.my, hxz * s.mx);
+            s.lx = fmaf(a.ds, fmaf(dn, m.gx, m.n * hmx), s.lx);
+            s.ly = fmaf(a.ds, fmaf(dn, m.gy, m.n * hmy), s.ly);
+            s.lz = fmaf(a.ds, fmaf(dn, m.gz, m.n * hmz), s.lz);
+            s.mx = fmaf(a.ds, s.lx, s.mx); s.my = fmaf(a.ds, s.ly, s.my); s.mz = fmaf(a.ds, s.lz, s.mz);
+            // ---- the ray leaves its cell ----
+            if (nbase != old_base || !interior) {
+              base = nbase; regular = nregular;
+              const int d = nbase - old_base;
+              if (d != 0 || regular != old_regular) {
+                const bool ax = (d == 1) | (d == -1), ay = (d == V.sy) | (d == -V.sy), az = (d == V.sz) | (d == -V.sz);
+                if (old_regular) {
+                  if (regular & (ax | ay | az) & (experiment != 1) & (experiment != 4)) {
+                    // one face crossed: emit the face left behind, carry the shared one
+                    const bool fwd = d > 0;
+                    // emitted corners e0..e3 and carried ones, in (p, q) in-face order; LDS / grid strides of p, q and of the axis
+                    float e0, e1, e2, e3;
+                    int lp, lq, la, gp, gq, ga;
+                    if (ay) {
+                      const f2 ea = fwd ? p00 : p10, eb = fwd ? p01 : p11;
+                      e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
+                      const f2 ka = fwd ? p10 : p00, kb = fwd ? p11 : p01;
+                      p00 = fwd ? ka : f2{0.f, 0.f}; p01 = fwd ? kb : f2{0.f, 0.f};
+                      p10 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
+                      lp = 1; lq = WSZ; la = WSY; gp = 1; gq = V.sz; ga = V.sy;
+                    } else if (az) {
+                      const f2 ea = fwd ? p00 : p01, eb = fwd ? p10 : p11;
+                      e0 = ea.x; e1 = ea.y; e2 = eb.x; e3 = eb.y;
+                      const f2 ka = fwd ? p01 : p00, kb = fwd ? p11 : p10;
+                      p00 = fwd ? ka : f2{0.f, 0.f}; p10 = fwd ? kb : f2{0.f, 0.f};
+                      p01 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
+                      lp = 1; lq = WSY; la = WSZ; gp = 1; gq = V.sy; ga = V.sz;
+                    } else {
+                      e0 = fwd ? p00.x : p00.y; e1 = fwd ? p10.x : p10.y; e2 = fwd ? p01.x : p01.y; e3 = fwd ? p11.x : p11.y;
+                      p00 = fwd ? f2{p00.y, 0.f} : f2{0.f, p00.x}; p10 = fwd ? f2{p10.y, 0.f} : f2{0.f, p10.x};
+                      p01 = fwd ? f2{p01.y, 0.f} : f2{0.f, p01.x}; p11 = fwd ? f2{p11.y, 0.f} : f2{0.f, p11.x};
+                      lp = WSY; lq = WSZ; la = 1; gp = V.sy; gq = V.sz; ga = 1;
+                    }
+                    if (old_lidx >= 0) {
+                      if (experiment != 3) {
+                        const int qi = old_lidx + (fwd ? 0 : la);
+                        // pair / quad pre-reduction (see shift_emit4): lanes of a quad that go to the same four slots
+                        const int key = qi | ((ay ? 1 : (az ? 2 : 0)) << 16);
+                        const int k1 = __builtin_amdgcn_update_dpp(-1, key, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+                        const int k2 = __builtin_amdgcn_update_dpp(-1, key, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+                        const int k3 = __builtin_amdgcn_update_dpp(-1, key, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+                        const bool psame = k1 == key;
+                        const bool same = psame & (k2 == key) & (k3 == key);
+                        float q0 = e0, q1 = e1, q2 = e2, q3 = e3;
+                        q0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q0), 0xB1, 0xF, 0xF, false));
+                        q1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1), 0xB1, 0xF, 0xF, false));
+                        q2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q2), 0xB1, 0xF, 0xF, false));
+                        q3 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q3), 0xB1, 0xF, 0xF, false));
+                        const float s0 = q0 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q0), 0x4E, 0xF, 0xF, false));
+                        const float s1 = q1 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q1), 0x4E, 0xF, 0xF, false));
+                        const float s2 = q2 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q2), 0x4E, 0xF, 0xF, false));
+                        const float s3 = q3 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q3), 0x4E, 0xF, 0xF, false));
+                        const unsigned ql = threadIdx.x & 3u;
+                        const bool add = same ? ql == 0u : (psame ? (ql & 1u) == 0u : true);
+                        if (experiment == 6) {            // ablation: no pre-reduction, every lane adds its own values
+                          win_t* q = win + qi;
+                          atomicAdd(q, (win_t)e0); atomicAdd(q + lp, (win_t)e1); atomicAdd(q + lq, (win_t)e2); atomicAdd(q + lq + lp, (win_t)e3);
+                        } else if (add) {
+                          win_t* q = win + qi;
+                          atomicAdd(q, (win_t)(same ? s0 : (psame ? q0 : e0)));      atomicAdd(q + lp, (win_t)(same ? s1 : (psame ? q1 : e1)));
+                          atomicAdd(q + lq, (win_t)(same ? s2 : (psame ? q2 : e2))); atomicAdd(q + lq + lp, (win_t)(same ? s3 : (psame ? q3 : e3)));
+                        }
+                      }
+                      used_lds = experiment != 5;         // ablation 5: never flush (until the end)
+                    } else if (experiment != 2) {
+                      float* g = a.grad + old_base + (fwd ? 0 : ga);
+                      atomic_add_f32(g, e0); atomic_add_f32(g + gp, e1); atomic_add_f32(g + gq, e2); atomic_add_f32(g + gq + gp, e3);
+                    }
+                  } else {
+                    // jump over more than one face, or into a clamped cell: hand over all eight
+                    if (experiment != 1) used_lds = flat_emit8(win, WSY, WSZ, a.grad, V.sy, V.sz, old_lidx, old_base, p00, p10, p01, p11);
+                    p00 = p10 = p01 = p11 = f2{0.f, 0.f};
+                  }
+                }
+                lidx = regular ? WIN_INDEX(ix, iy, iz) : -1;
+                miss = regular & (lidx < 0);
+              }
             }
           }
         }
       }
+      dirty = dirty | (__ballot(used_lds) != 0ull);
     }
-    dirty = dirty | (__ballot(used_lds) != 0ull);
-  }
-#undef DRRT_FLAT_STEP_LOCATE
+#undef WSY
+#undef WSZ
+#undef WIN_INDEX
   // rays still marching when max_steps ran out keep what their cell has accumulated: hand it over
-  if (s.active && regular && experiment != 1) { if (flat_emit8(win, a.grad, V.sy, V.sz, lidx, base, p00, p10, p01, p11)) dirty = true; }
+  if (s.active && regular && experiment != 1) { if (flat_emit8(win, W.sy, W.sz, a.grad, V.sy, V.sz, lidx, base, p00, p10, p01, p11)) dirty = true; }
   dirty = __ballot(dirty) != 0ull;
-  if (dirty) { win_flush(win, wox, woy, woz, a.grad, V, lane, experiment == 2); ++n_flush; }
+  if (dirty) {
+    if constexpr (DYN) win_flush_dyn(win, W, a.grad, V, lane, experiment == 2);
+    else win_flush(win, W.ox, W.oy, W.oz, a.grad, V, lane, experiment == 2);
+    ++n_flush;
+  }
   if (ABL && a.dbg) {
     if (lane == 0) atomicAdd(&a.dbg[0], (unsigned long long)n_flush);
+    if (DYN && lane == 0) atomicAdd(&a.dbg[3], 1ull);          // waves that ran with run-time window dimensions
   }
   block_stats(a.stats, steps, 0u);
 }
@@ -1830,10 +1997,27 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
     else if (MODE == 0 && !(flags & DRRT_FLAG_LEGACY_ADJOINT)) {
       const bool abl = a.experiment != 0 || a.dbg != nullptr, pair = a.vol.pair != nullptr;
       const dim3 g(grid_for(n));
-      if (abl) { if (pair) hipLaunchKernelGGL((k_backtrace_flat<true, true>), g, dim3(kBlock), 0, s, a);
-                 else      hipLaunchKernelGGL((k_backtrace_flat<true, false>), g, dim3(kBlock), 0, s, a); }
-      else     { if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true>), g, dim3(kBlock), 0, s, a);
-                 else      hipLaunchKernelGGL((k_backtrace_flat<false, false>), g, dim3(kBlock), 0, s, a); }
+      // With a visit order the bundles are classified on the device and BOTH window variants are launched; the one the
+      // counters do not pick returns at once (no host round trip).  Needs the 512-byte counter block at the end of a
+      // drrt_workspace_bytes_grid() workspace; without it, or without an order, the compile-time-window kernel runs.
+      a.select = nullptr;
+      const size_t ctr_off = (drrt_workspace_bytes(n, flags) + ((flags & DRRT_FLAG_PAIR_GRID) ? (size_t)nvox * 2 * sizeof(float) : 0) + 7) & ~(size_t)7;
+      if (a.perm != nullptr && ws && ws_bytes >= ctr_off + 512 && !(flags & DRRT_FLAG_STATIC_WINDOW) && a.experiment != 7) {
+        a.select = (unsigned*)((char*)ws + ctr_off + 256);
+        hipError_t e = hipMemsetAsync(a.select, 0, 8, s);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(select)");
+        hipLaunchKernelGGL(k_bundle_classify, dim3((g.x + kClassifyStride - 1) / kClassifyStride), dim3(kBlock), 0, s, a);
+      }
+#define DRRT_LAUNCH_FLAT(DYN)                                                                                         \
+      do {                                                                                                            \
+        if (abl) { if (pair) hipLaunchKernelGGL((k_backtrace_flat<true, true, DYN>), g, dim3(kBlock), 0, s, a);       \
+                   else      hipLaunchKernelGGL((k_backtrace_flat<true, false, DYN>), g, dim3(kBlock), 0, s, a); }    \
+        else     { if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true, DYN>), g, dim3(kBlock), 0, s, a);      \
+                   else      hipLaunchKernelGGL((k_backtrace_flat<false, false, DYN>), g, dim3(kBlock), 0, s, a); }   \
+      } while (0)
+      DRRT_LAUNCH_FLAT(false);
+      if (a.select != nullptr) DRRT_LAUNCH_FLAT(true);
+#undef DRRT_LAUNCH_FLAT
     }
     else if (a.experiment != 0 || a.dbg != nullptr)
       hipLaunchKernelGGL((k_backtrace_win<MODE, true, true>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);

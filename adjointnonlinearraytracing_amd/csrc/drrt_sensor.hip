@@ -429,3 +429,79 @@ extern "C" int drrt_adam_step_f32(float* param, float* grad, float* exp_avg, flo
   return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
 }
 
+// =============================================================================================
+// ray -> plane intersection as its own operator (the statement right after the march)
+//
+// Reference: core/sensor.py:195-202 trace_rays_to_plane: t = n.(p - x) / n.v ; x_out = x + t v ; v unchanged --
+// written with torch.matmul on (N,1,3) x (N,3,1) operands, i.e. a batched matmul of N one-by-three products, which on
+// the GPU costs ~25 ms forward and ~55 ms backward for 1M rays (tools/bench_iteration.py): 15x the march itself.
+// Here: one thread per ray, forward and analytic backward (gradients w.r.t. the rays; the planes are constants in
+// every experiment of the reference -- the Python wrapper falls back to the torch expressions if they require grad):
+//   a = n.(p - x), b = n.v, t = a / b
+//   d x_out / d x = I - v n^T / b            d x_out / d v = t I - (t / b) v n^T
+//   => gx = g - (g.v / b) n                  gv = t g - (t / b)(g.v) n          (g = dL/dx_out)
+// plane_stride = 3: one plane per ray; 0: one plane for all rays.
+// =============================================================================================
+namespace drrt {
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+  return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+
+__global__ void __launch_bounds__(256) k_rays_to_plane(size_t n, const float* __restrict__ x, const float* __restrict__ v,
+                                                       const float* __restrict__ p, const float* __restrict__ nr,
+                                                       int plane_stride, float* __restrict__ xo) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t k = i * (size_t)plane_stride;
+  const float x0 = x[3 * i], x1 = x[3 * i + 1], x2 = x[3 * i + 2], v0 = v[3 * i], v1 = v[3 * i + 1], v2 = v[3 * i + 2];
+  const float n0 = nr[k], n1 = nr[k + 1], n2 = nr[k + 2];
+  const float a = dot3(n0, n1, n2, p[k] - x0, p[k + 1] - x1, p[k + 2] - x2);        // :199
+  const float t = a / dot3(n0, n1, n2, v0, v1, v2);                                   // :200
+  xo[3 * i] = fmaf(t, v0, x0); xo[3 * i + 1] = fmaf(t, v1, x1); xo[3 * i + 2] = fmaf(t, v2, x2);   // :202
+}
+
+__global__ void __launch_bounds__(256) k_rays_to_plane_bwd(size_t n, const float* __restrict__ x, const float* __restrict__ v,
+                                                           const float* __restrict__ p, const float* __restrict__ nr,
+                                                           int plane_stride, const float* __restrict__ g,
+                                                           float* __restrict__ gx, float* __restrict__ gv) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t k = i * (size_t)plane_stride;
+  const float x0 = x[3 * i], x1 = x[3 * i + 1], x2 = x[3 * i + 2], v0 = v[3 * i], v1 = v[3 * i + 1], v2 = v[3 * i + 2];
+  const float n0 = nr[k], n1 = nr[k + 1], n2 = nr[k + 2];
+  const float g0 = g[3 * i], g1 = g[3 * i + 1], g2 = g[3 * i + 2];
+  const float a = dot3(n0, n1, n2, p[k] - x0, p[k + 1] - x1, p[k + 2] - x2);
+  const float inv_b = 1.f / dot3(n0, n1, n2, v0, v1, v2);
+  const float t = a * inv_b;
+  const float c = dot3(g0, g1, g2, v0, v1, v2) * inv_b;       // g.v / b
+  gx[3 * i] = fmaf(-c, n0, g0); gx[3 * i + 1] = fmaf(-c, n1, g1); gx[3 * i + 2] = fmaf(-c, n2, g2);
+  const float tc = t * c;
+  gv[3 * i] = fmaf(t, g0, -tc * n0); gv[3 * i + 1] = fmaf(t, g1, -tc * n1); gv[3 * i + 2] = fmaf(t, g2, -tc * n2);
+}
+
+}  // namespace drrt
+
+extern "C" int drrt_rays_to_plane_f32(size_t n, const float* x, const float* v, const float* plane_p, const float* plane_n,
+                                      int plane_stride, float* x_out, void* stream) {
+  if (plane_stride != 0 && plane_stride != 3) return sensor_fail(DRRT_ERR_ARG, "plane_stride must be 0 or 3");
+  if (n == 0) return DRRT_OK;
+  if (!x || !v || !plane_p || !plane_n || !x_out) return sensor_fail(DRRT_ERR_ARG, "null pointer");
+  hipLaunchKernelGGL(drrt::k_rays_to_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, x, v,
+                     plane_p, plane_n, plane_stride, x_out);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+
+extern "C" int drrt_rays_to_plane_bwd_f32(size_t n, const float* x, const float* v, const float* plane_p,
+                                          const float* plane_n, int plane_stride, const float* grad_x_out,
+                                          float* grad_x, float* grad_v, void* stream) {
+  if (plane_stride != 0 && plane_stride != 3) return sensor_fail(DRRT_ERR_ARG, "plane_stride must be 0 or 3");
+  if (n == 0) return DRRT_OK;
+  if (!x || !v || !plane_p || !plane_n || !grad_x_out || !grad_x || !grad_v) return sensor_fail(DRRT_ERR_ARG, "null pointer");
+  hipLaunchKernelGGL(drrt::k_rays_to_plane_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, x,
+                     v, plane_p, plane_n, plane_stride, grad_x_out, grad_x, grad_v);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+

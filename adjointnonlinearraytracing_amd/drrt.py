@@ -81,7 +81,12 @@ def _flags(adjoint: bool = False) -> int:
         f |= _lib.FLAG_LEGACY_ADJOINT
     if not adjoint and options.lds_bricks:
         f |= _lib.FLAG_LDS_BRICKS
+    if adjoint and _EXPERIMENT:
+        f |= (_EXPERIMENT & 0xFF) << 8          # development ablations of the adjoint kernel (include/drrt_hip.h)
     return f
+
+
+_EXPERIMENT = 0
 
 
 def _workspace(n: int, flags: int, device: torch.device, nvox: int = 0) -> torch.Tensor:

@@ -18,10 +18,54 @@ import torch
 from . import _lib
 
 
+class _RaysToPlane(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, v, p, n):
+        dev = x.device
+        with torch.cuda.device(dev):
+            x_ = x.detach().to(torch.float32).contiguous()
+            v_ = v.detach().to(torch.float32).contiguous()
+            p_ = p.detach().to(device=dev, dtype=torch.float32).contiguous()
+            n_ = n.detach().to(device=dev, dtype=torch.float32).contiguous()
+            stride = 3 if p_.shape[0] > 1 else 0
+            xo = torch.empty_like(x_)
+            _lib.check(_lib.load().drrt_rays_to_plane_f32(
+                x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()), C.c_void_p(p_.data_ptr()),
+                C.c_void_p(n_.data_ptr()), stride, C.c_void_p(xo.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.save_for_backward(x_, v_, p_, n_)
+        ctx.stride = stride
+        return xo
+
+    @staticmethod
+    def backward(ctx, g):
+        x_, v_, p_, n_ = ctx.saved_tensors
+        dev = x_.device
+        with torch.cuda.device(dev):
+            g_ = g.detach().to(torch.float32).contiguous()
+            gx, gv = torch.empty_like(x_), torch.empty_like(v_)
+            _lib.check(_lib.load().drrt_rays_to_plane_bwd_f32(
+                x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()), C.c_void_p(p_.data_ptr()),
+                C.c_void_p(n_.data_ptr()), ctx.stride, C.c_void_p(g_.data_ptr()), C.c_void_p(gx.data_ptr()),
+                C.c_void_p(gv.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return gx, gv, None, None
+
+
 def trace_rays_to_plane(rays, plane):
-    """core/sensor.py:195-202 (plain torch, unchanged semantics)."""
+    """core/sensor.py:195-202: intersect the rays with their planes, ``(x + t v, v)`` with ``t = n.(p - x) / n.v``.
+
+    The reference writes the two dot products as ``torch.matmul`` on (N,1,3) x (N,3,1) operands -- a batched matmul of
+    N one-by-three products, ~25 ms forward + ~55 ms backward for 1M rays on this GPU, 15x the march.  For fp32 (N,3)
+    rays on the cuda (ROCm) device with (N,3) or (1,3) planes that are constants (they are in every experiment of the
+    reference) this runs one fused HIP kernel each way; any other input takes the reference's torch expressions."""
     x, v = rays
     p, n = plane
+    fused = (x.is_cuda and x.dtype == torch.float32 and v.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 3
+             and v.shape == x.shape and p.dim() == 2 and n.dim() == 2 and p.shape == n.shape and p.shape[1] == 3
+             and p.shape[0] in (1, x.shape[0]) and not p.requires_grad and not n.requires_grad)
+    if fused:
+        return _RaysToPlane.apply(x, v, p, n), v
     t = torch.matmul(n[:, None, :], (p - x)[:, :, None]).squeeze(2)
     t = t / torch.matmul(n[:, None, :], v[:, :, None]).squeeze(2)
     return (x + t * v), v

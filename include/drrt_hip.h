@@ -85,12 +85,16 @@ extern "C" {
 #define DRRT_FLAG_Q16_POS_ONLY 0x200000u  /* drrt_trace_q16io / drrt_backtrace_q16io: only the POSITION arrays are q16 codes;
                                              directions and adjoint seeds are fp32 arrays (18 B per exit ray instead of 12) */
 #define DRRT_FLAG_LEGACY_FORWARD 0x100000u /* trace (A-B measurement; bit-identical results): k_trace<0> instead of k_trace_flat */
+#define DRRT_FLAG_STATIC_WINDOW 0x400000u  /* backtrace (A-B measurement; same results up to fp32 summation order): always the
+                                             kernel with compile-time 9^3 gradient windows, no per-call bundle classification */
 #define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace (A-B measurement; same results up to fp32 summation order): the round-1
                                              window kernel k_backtrace_win instead of the reorganised k_backtrace_flat */
-#define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): three uint64 counters are
+#define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): uint64 counters are
                                        written to the last 512 bytes of the workspace:
                                        [0] LDS-window flushes, [1] ray-steps accumulated through
-                                       the LDS window, [2] ray-steps that fell back to global atomics.
+                                       the LDS window, [2] ray-steps that fell back to global atomics
+                                       ([1], [2]: round-1 kernel only), [3] waves that ran with
+                                       run-time window dimensions (fitted windows).
                                        Bits 8..15 of `flags` select development ablations (0 = product) */
 
 /* Limits (violations are refused with DRRT_ERR_ARG and a message, never truncated silently):
@@ -294,6 +298,15 @@ DRRT_API int drrt_sensor_far_splat_f32(size_t n, const float* v, const float* e,
 DRRT_API int drrt_sensor_far_splat_bwd_f32(size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
                                   const float t2[3], int res, float ang_cut, const float* grad_image,
                                   float* grad_x, float* grad_v, void* stream);
+
+/* core/sensor.py:195-202 trace_rays_to_plane, the statement right after the march in every experiment: x_out = x + t v with
+ * t = n.(p - x) / n.v (v passes through unchanged), and its analytic backward w.r.t. the rays (grad_x, grad_v receive the
+ * part of the gradient that flows through x_out).  plane_stride 3 = one (p, n) per ray, 0 = one plane for all rays.
+ * All pointers are device pointers to fp32 (n,3) row-major arrays (planes: (n,3) or (1,3)).                        */
+DRRT_API int drrt_rays_to_plane_f32(size_t n, const float* x, const float* v, const float* plane_p, const float* plane_n,
+                           int plane_stride, float* x_out, void* stream);
+DRRT_API int drrt_rays_to_plane_bwd_f32(size_t n, const float* x, const float* v, const float* plane_p, const float* plane_n,
+                               int plane_stride, const float* grad_x_out, float* grad_x, float* grad_v, void* stream);
 
 /* ---- multires up-sampling (SURVEY.md 8.8 "next" row 3) --------------------------------------------
  * core/optimizer.py:7-10 upres_scene / core/grid.py:318-330 upres_volume: trilinear resampling of a

@@ -271,6 +271,33 @@ def sensor_far():
     save("sensor_far.npz", **out)
 
 
+def rays_to_plane():
+    """core/sensor.py trace_rays_to_plane (:195-202) and torch.autograd through it RUN AS IS (float64, CPU): the
+    statement right after the march in every experiment (core/image_opt.py:95, core/luneburg_opt.py:97), with per-ray
+    planes (a) and one broadcast plane (b)."""
+    torch.manual_seed(6)
+    out = {}
+    for tag, per_ray in (("a", True), ("b", False)):
+        N = 900
+        x = torch.rand(N, 3, dtype=torch.float64)
+        v = torch.randn(N, 3, dtype=torch.float64) * 0.3
+        v[:, 1] = 1.0
+        v = v * (0.8 + 0.6 * torch.rand(N, 1, dtype=torch.float64))
+        M = N if per_ray else 1
+        p = torch.tensor([[0.5, 1.3, 0.5]], dtype=torch.float64) + 0.05 * torch.randn(M, 3, dtype=torch.float64)
+        n = torch.tensor([[0.05, 1.0, -0.1]], dtype=torch.float64) + 0.1 * torch.randn(M, 3, dtype=torch.float64)
+        n = n / n.norm(dim=1, keepdim=True)
+        x.requires_grad_(True); v.requires_grad_(True)
+        xo, vo = ref_sensor.trace_rays_to_plane((x, v), (p, n))
+        gx, gv = torch.randn_like(xo), torch.randn_like(vo)
+        ((xo * gx).sum() + (vo * gv).sum()).backward()
+        out.update({f"{tag}_x": x.detach().numpy(), f"{tag}_v": v.detach().numpy(), f"{tag}_p": p.numpy(),
+                    f"{tag}_n": n.numpy(), f"{tag}_xo": xo.detach().numpy(), f"{tag}_vo": vo.detach().numpy(),
+                    f"{tag}_gxo": gx.numpy(), f"{tag}_gvo": gv.numpy(), f"{tag}_gx": x.grad.numpy(),
+                    f"{tag}_gv": v.grad.numpy()})
+    save("rays_to_plane.npz", **out)
+
+
 def source_rays():
     """core/source.py generators RUN AS IS; `u_*` are the uniforms they drew (same seed replayed)."""
     out = {}
@@ -351,6 +378,7 @@ if __name__ == "__main__":
     fuel_injection()
     sensor_splat()
     sensor_far()
+    rays_to_plane()
     cone_rays()
     upres()
     source_rays()

@@ -781,3 +781,58 @@ def test_q16_ray_state_mode(gpu, drrt_mod):
     assert cases.rel_l2(g_q.cpu().numpy(), g_f.cpu().numpy()) <= 2e-5
     with pytest.raises(RuntimeError, match="float16 seeds"):
         T.backtrace(rif, rif.shape, xt_q, vt_q, dx.float(), dv.float(), h, ds)
+
+
+def test_fitted_windows_for_oblique_views(gpu):
+    """A plane view oblique to the grid with few rays per voxel column: the 64-ray bundles start the adjoint staggered on
+    an oblique exit face and do not fit the default 9^3 gradient window.  The call must pick the kernel with run-time
+    window dimensions (debug counter [3]), a dense axis-aligned view must not, and both must return the gradient of
+    the one-atomic-per-tap kernel and of the compile-time-window kernel (fp32 summation order only)."""
+    import ctypes as C
+    from adjointnonlinearraytracing_amd import _lib, source
+    lib = _lib.load()
+    R = 96
+    span = 1.0; h = span / (R - 1); ds = h / 2
+    g = torch.linspace(0.0, 1.0, R, device=gpu)
+    z, y, x = torch.meshgrid(g, g, g, indexing="ij")
+    rif = (1.0 + 0.05 * torch.exp(-((x - 0.45) ** 2 + (y - 0.55) ** 2 + (z - 0.5) ** 2) / 0.03)).contiguous()
+    nvox = rif.numel(); res = (C.c_int * 3)(R, R, R)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+    fitted_waves = {}
+    for ang, pix in ((0.0, 2 * R), (40.0, R)):                       # 16 / 4 rays per voxel column
+        xs, vs, _ = source.plane_source3_rand(torch.tensor(ang), (pix, pix), 4, span, sensor_dist=0.2 * span, device=gpu)
+        xs, vs = xs.contiguous(), vs.contiguous()
+        nr = xs.shape[0]
+        flags = _lib.FLAG_SORT_RAYS
+        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(nr, nvox, flags)), dtype=torch.uint8, device=gpu)
+        xt, vt = torch.empty_like(xs), torch.empty_like(vs)
+        st = torch.zeros(3, dtype=torch.int64, device=gpu)
+        _lib.check(lib.drrt_trace_f32(p(rif), nvox, res, nr, p(xs), p(vs), h, ds, p(xt), p(vt), p(st), p(ws), ws.numel(),
+                                      flags, stream))
+        cnt = C.c_size_t(0)
+        src = lib.drrt_last_order(C.byref(cnt))
+        assert cnt.value == nr
+        order = torch.empty(nr, dtype=torch.int32, device=gpu)
+        torch.cuda.synchronize()
+        wsi = ws.view(torch.int32)
+        off = (src - ws.data_ptr()) // 4
+        order.copy_(wsi[off:off + nr])
+        gen = torch.Generator().manual_seed(3)
+        dx = torch.randn(nr, 3, generator=gen).to(gpu); dv = torch.randn(nr, 3, generator=gen).to(gpu)
+        grads = {}
+        for name, fl in (("auto", flags | _lib.FLAG_DEBUG_COUNTERS), ("static", flags | _lib.FLAG_STATIC_WINDOW),
+                         ("direct", flags | _lib.FLAG_DIRECT_ATOMICS)):
+            grad = torch.empty(nvox, dtype=torch.float32, device=gpu)
+            lib.drrt_set_order_hint(p(order), nr)
+            _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, nr, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad), p(st),
+                                              p(ws), ws.numel(), fl, stream))
+            torch.cuda.synchronize()
+            grads[name] = grad.cpu().numpy().astype(np.float64)
+            if name == "auto":
+                o = (ws.numel() - 512) & ~7
+                fitted_waves[ang] = int(ws[o:o + 512].view(torch.int64)[3])
+        assert cases.rel_l2(grads["auto"], grads["direct"]) <= 2e-6, ang
+        assert cases.rel_l2(grads["static"], grads["direct"]) <= 2e-6, ang
+    assert fitted_waves[0.0] == 0, fitted_waves                       # dense axis-aligned bundles fit the default window
+    assert fitted_waves[40.0] > 0, fitted_waves                       # the oblique view runs with fitted windows

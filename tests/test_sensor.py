@@ -206,3 +206,42 @@ def test_hip_far_sensor_full_size(gpu):
     img_s = sensor.generate_inf_sensor((x[sub], v[sub]), 1, (p, nn), res, 120, tt)
     ref = S.generate_inf_sensor(v[sub].cpu().numpy(), 1.0, nn.cpu().numpy(), res, 120, tt.cpu().numpy())
     assert cases.rel_l2(img_s.cpu().numpy(), ref) <= 1e-4
+
+
+# ---- trace_rays_to_plane (core/sensor.py:195-202): the statement right after the march -------------------------------
+GP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rays_to_plane.npz")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_rays_to_plane_torch_path_matches_reference_run(tag):
+    """CPU tensors (and any input the fused kernel does not take) run the reference's own torch expressions: they
+    reproduce the fixture made by RUNNING core/sensor.py trace_rays_to_plane + autograd (float64)."""
+    from adjointnonlinearraytracing_amd import sensor
+    z = np.load(GP)
+    x = torch.from_numpy(z[f"{tag}_x"]).requires_grad_(True)
+    v = torch.from_numpy(z[f"{tag}_v"]).requires_grad_(True)
+    xo, vo = sensor.trace_rays_to_plane((x, v), (torch.from_numpy(z[f"{tag}_p"]), torch.from_numpy(z[f"{tag}_n"])))
+    ((xo * torch.from_numpy(z[f"{tag}_gxo"])).sum() + (vo * torch.from_numpy(z[f"{tag}_gvo"])).sum()).backward()
+    assert np.abs(xo.detach().numpy() - z[f"{tag}_xo"]).max() < 1e-13
+    assert np.abs(x.grad.numpy() - z[f"{tag}_gx"]).max() < 1e-12 and np.abs(v.grad.numpy() - z[f"{tag}_gv"]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_rays_to_plane_fused_matches_reference_run(gpu, tag):
+    """fp32 rays on the device take the fused HIP kernels (forward + analytic backward): 4e-6 relative to the fixture
+    (fp32 rounding of t = a / b and of the products), per-ray planes and one broadcast plane; v passes through."""
+    from adjointnonlinearraytracing_amd import sensor
+    z = np.load(GP)
+    f = lambda k: torch.from_numpy(z[f"{tag}_{k}"]).to(torch.float32).to(gpu)
+    x, v = f("x").requires_grad_(True), f("v").requires_grad_(True)
+    xo, vo = sensor.trace_rays_to_plane((x, v), (f("p"), f("n")))
+    assert vo is v and xo.grad_fn is not None and type(xo.grad_fn).__name__.startswith("_RaysToPlane")
+    ((xo * f("gxo")).sum() + (vo * f("gvo")).sum()).backward()
+    for got, want in ((xo.detach(), z[f"{tag}_xo"]), (x.grad, z[f"{tag}_gx"]), (v.grad, z[f"{tag}_gv"])):
+        assert np.abs(got.cpu().numpy() - want).max() <= 4e-6 * np.abs(want).max(), tag
+    # planes that require grad fall back to the torch expressions (their gradients exist, as in the reference)
+    p = f("p").requires_grad_(True)
+    xo2, _ = sensor.trace_rays_to_plane((x.detach(), v.detach()), (p, f("n")))
+    xo2.sum().backward()
+    assert p.grad is not None and torch.allclose(xo2.detach(), xo.detach(), rtol=1e-5, atol=1e-6)
