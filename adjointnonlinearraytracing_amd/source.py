@@ -16,8 +16,14 @@ compaction included) instead of on the host followed by an upload.  Keyword-only
 * ``rotmat``  -- a 3x3 matrix: fuses ``random_rotate_ic`` into the generation (saves a second pass
   over the 15 floats per ray).
 
-The deterministic point source and the area sources (``:29-51``, ``:107-185``, ``:206-272``) are not on the
-accelerated path: ``rand_rays_cube`` with ``src_type == 'point'`` raises ``NotImplementedError``.
+The area sources of the image / focal-stack / fuel-injection experiments -- ``area_source3_rand_bias`` (``:107-150``),
+``area_source3_cone`` (``:152-183``), ``rand_area_in_sphere`` (``:368-376``), ``rand_cone_in_sphere`` (``:379-385``) --
+and ``sum_norm`` (``:415-420``) are the reference's element-wise torch expressions evaluated ON the device (they contain
+no gather and no batched matmul, so there is nothing for a hand-written kernel to win); their keyword-only ``offset`` /
+``tosense`` / ``hatbox`` arguments take the uniform draws, so the reference's draws reproduce its rays.
+
+The deterministic point source (``:29-51``) is not provided: ``rand_rays_cube`` with ``src_type == 'point'`` raises
+``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -186,3 +192,110 @@ def random_rotate_ic(x, v, planes, span, rotmat=None):
     sn = torch.matmul(rotmat, planes[:, 1, :, None])
     st = torch.matmul(rotmat, planes[:, 2, :, None])
     return xn.squeeze(-1), vn.squeeze(-1), torch.stack([sp.squeeze(-1), sn.squeeze(-1), st.squeeze(-1)], dim=1)
+
+
+# ---- area sources and image normalisation: the reference's torch expressions, on the device -------------------------
+def sum_norm(im, scale=False):
+    """core/source.py:415-420: scale the image to unit mean."""
+    scalar = torch.numel(im) / im.sum()
+    if scale:
+        return scalar * im, scalar
+    return scalar * im
+
+
+def _area_points(pixels, spp, width, circle, y_value, offset, dev):
+    """Jittered pixel-centre samples of the source plane (:108-120 / :153-165): (N,3) points and the disc mask."""
+    p0, p1, spp = int(pixels[0]), int(pixels[1]), int(spp)
+    u = torch.rand(2 * spp, p0, p1, device=dev) if offset is None else \
+        offset.detach().to(device=dev, dtype=torch.float32).reshape(2 * spp, p0, p1)
+    off = (u - 0.5) * (width / p0)
+    rng = [width * ((torch.arange(p, device=dev) + 0.5) / p - 0.5) for p in (p0, p1)]
+    g0, g1 = torch.meshgrid(*rng, indexing="ij")
+    pts = [g0 + off[:spp], torch.full((p0, p1, spp), float(y_value), device=dev), g1 + off[spp:]]
+    pos = torch.stack([q.flatten() for q in pts], dim=-1)
+    if circle:
+        pos = pos[torch.norm(pos, dim=-1) < (width / 2)]
+    return pos
+
+
+def _planes_of_view(n, angle, xaxis, width, sensor_dist, dev):
+    e_y = torch.tensor([0.0, 1.0, 0.0], device=dev).repeat(n, 1)
+    e_z = torch.tensor([0.0, 0.0, 1.0], device=dev).repeat(n, 1)
+    plane_v = rotate_ray3(e_y, angle, vert=xaxis)
+    plane_t = rotate_ray3(e_z, angle, vert=xaxis)
+    plane_x = (sensor_dist + width / 2) * plane_v + width / 2
+    return torch.stack([plane_x, plane_v, plane_t], dim=1)
+
+
+def area_source3_rand_bias(angle, pixels, spp, width, circle=False, xaxis=False, sensor_dist=1.0, *, offset=None,
+                           tosense=None, device=None):
+    """core/source.py:107-150 -> ((x, v, planes), xt, tpv): every source sample aims at a random point of the far face."""
+    dev = torch.device("cuda" if device is None else device)
+    pos = _area_points(pixels, spp, width, circle, 0.0, offset, dev)
+    n = pos.shape[0]
+    up = torch.tensor([[0.0, 1.0, 0.0]], device=dev)
+    pt = -pos + (sensor_dist + width / 2) * up                                     # :122, :124
+    pos = pos - (sensor_dist + width / 2) * up                                     # :123
+    ts = torch.rand(2, n, device=dev) if tosense is None else tosense.detach().to(device=dev, dtype=torch.float32).reshape(2, n)
+    ts = (ts - 0.5) * (1.0 * width)                                                # :126-127
+    target = torch.stack([ts[0], width * torch.ones(n, device=dev) / 2, ts[1]], dim=-1)
+    vel = target - pos
+    vel = vel / torch.norm(vel, dim=-1, keepdim=True)
+    tpv = sensor_dist / vel[..., 1]
+    npos = pos + tpv[:, None] * vel
+    xt = rotate_ray3(pt, angle, vert=xaxis) + width / 2
+    x = rotate_ray3(npos, angle, vert=xaxis) + width / 2
+    v = rotate_ray3(vel, angle, vert=xaxis)
+    return (x, v, _planes_of_view(n, angle, xaxis, width, sensor_dist, dev)), xt, tpv
+
+
+def hatbox_sample(v, angle, *, draws=None):
+    """core/source.py:531-545: directions uniformly distributed in the cone of full angle ``angle`` around ``v``."""
+    dev = v.device
+    basis = torch.tensor([[0.0, 0.0, 1.0]], device=dev)
+    dist = torch.cos(torch.deg2rad(torch.tensor(float(angle))) / 2).to(dev)
+    u = torch.rand(2, v.shape[0], device=dev) if draws is None else draws.detach().to(device=dev, dtype=torch.float32).reshape(2, -1)
+    z = u[0] * (1 - dist) + dist
+    theta = 2 * np.pi * u[1]
+    scale = torch.sqrt(1 - z ** 2)
+    cx, cy = torch.cos(theta) * scale, torch.sin(theta) * scale
+    t1 = torch.cross(basis.expand_as(v), v, dim=-1)
+    t2 = torch.cross(t1, v, dim=-1)
+    return cx[:, None] * t1 + cy[:, None] * t2 + z[:, None] * v
+
+
+def area_source3_cone(angle, pixels, spp, width, circle=False, xaxis=False, sensor_dist=1.0, cone_angle=90, *,
+                      offset=None, hatbox=None, device=None):
+    """core/source.py:152-183 -> ((x, v, planes), tpv): an area source on the near face emitting into a cone."""
+    dev = torch.device("cuda" if device is None else device)
+    pos = _area_points(pixels, spp, width, circle, -width / 2, offset, dev)
+    forward = torch.zeros_like(pos)
+    forward[:, 1] = 1
+    vel = hatbox_sample(forward, cone_angle, draws=hatbox)
+    tpv = sensor_dist / vel[..., 1]
+    x = rotate_ray3(pos, angle, vert=xaxis) + width / 2
+    v = rotate_ray3(vel, angle, vert=xaxis)
+    return (x, v, _planes_of_view(pos.shape[0], angle, xaxis, width, sensor_dist, dev)), tpv
+
+
+def rand_area_in_sphere(nviews, im_res, spp, width, angle_span=360, circle=False, xaxis=False, sensor_dist=1.0, *,
+                        device=None):
+    """core/source.py:368-376 -> ((x, v, planes), targets, dists, nrays)."""
+    angles = torch.linspace(0, angle_span, nviews + 1)
+    view_list = [area_source3_rand_bias(angles[i], im_res, spp, width, circle=circle, xaxis=xaxis,
+                                        sensor_dist=sensor_dist, device=device) for i in range(nviews)]
+    views, targets, dists = zip(*view_list)
+    nrays = [v[0].shape[0] for v in views]
+    return tuple(map(torch.cat, zip(*views))), torch.cat(targets), torch.cat(dists), nrays
+
+
+def rand_cone_in_sphere(nviews, im_res, spp, width, angle_span=360, circle=False, xaxis=False, sensor_dist=1.0,
+                        cone_angle=90.0, *, device=None):
+    """core/source.py:379-385 -> ((x, v, planes), dists, nrays)."""
+    angles = torch.linspace(0, angle_span, nviews + 1)
+    view_list = [area_source3_cone(angles[i], im_res, spp, width, circle=circle, xaxis=xaxis, sensor_dist=sensor_dist,
+                                   cone_angle=cone_angle, device=device) for i in range(nviews)]
+    views, dists = zip(*view_list)
+    nrays = [v[0].shape[0] for v in views]
+    return tuple(map(torch.cat, zip(*views))), torch.cat(dists), nrays
+

@@ -298,6 +298,32 @@ def rays_to_plane():
     save("rays_to_plane.npz", **out)
 
 
+def area_rays():
+    """core/source.py area_source3_rand_bias (:107-150) and area_source3_cone (:152-183) RUN AS IS (float32, CPU); `*_u*`
+    are the uniforms they drew: the host generator is re-seeded and the same torch.rand calls replayed."""
+    out = {}
+    for tag, circle, xaxis, ang in (("a", False, False, 30.0), ("b", True, True, 115.0)):
+        pix, spp, width, sd = (9, 7), 3, 2.0, 0.6
+        torch.manual_seed(11)
+        (x, v, pl), xt, tpv = ref_source.area_source3_rand_bias(torch.tensor(ang), pix, spp, width, circle=circle,
+                                                                 xaxis=xaxis, sensor_dist=sd)
+        torch.manual_seed(11)
+        u_off = torch.rand(2 * spp, pix[0], pix[1]); u_ts = torch.rand(2, x.shape[0])
+        out.update({f"bias_{tag}_x": x.numpy(), f"bias_{tag}_v": v.numpy(), f"bias_{tag}_planes": pl.numpy(),
+                    f"bias_{tag}_xt": xt.numpy(), f"bias_{tag}_tpv": tpv.numpy(), f"bias_{tag}_uoff": u_off.numpy(),
+                    f"bias_{tag}_uts": u_ts.numpy(), f"bias_{tag}_args": np.array([ang, pix[0], pix[1], spp, width, sd,
+                                                                                     float(circle), float(xaxis)])})
+        torch.manual_seed(12)
+        (x, v, pl), tpv = ref_source.area_source3_cone(torch.tensor(ang), pix, spp, width, circle=circle, xaxis=xaxis,
+                                                        sensor_dist=sd, cone_angle=70.0)
+        torch.manual_seed(12)
+        u_off = torch.rand(2 * spp, pix[0], pix[1]); u_z = torch.rand(x.shape[0]); u_th = torch.rand(x.shape[0])
+        out.update({f"cone_{tag}_x": x.numpy(), f"cone_{tag}_v": v.numpy(), f"cone_{tag}_planes": pl.numpy(),
+                    f"cone_{tag}_tpv": tpv.numpy(), f"cone_{tag}_uoff": u_off.numpy(),
+                    f"cone_{tag}_uhat": torch.stack([u_z, u_th]).numpy()})
+    save("area_rays.npz", **out)
+
+
 def source_rays():
     """core/source.py generators RUN AS IS; `u_*` are the uniforms they drew (same seed replayed)."""
     out = {}
@@ -379,6 +405,7 @@ if __name__ == "__main__":
     sensor_splat()
     sensor_far()
     rays_to_plane()
+    area_rays()
     cone_rays()
     upres()
     source_rays()

@@ -14,6 +14,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PIX, SPP = (12, 10), 2
@@ -238,3 +239,44 @@ def test_hip_cone_source_full_size_statistics(gpu, S, SR):
     assert vn[:, 1].min() >= np.cos(np.deg2rad(20.0)) - 1e-6
     xr, vr, plr = SR.cone_view(u.numpy(), SR.view_matrix(np.float32(0.0), False), pix, spp, width, sensor_dist=1.0, cone_angle=40.0)
     _close(vn, vr, 4 * ulps(1.0)); _close(_np(x), xr, ulps(width))
+
+
+# ---- area sources (core/source.py:107-183, :368-385) and sum_norm: the reference's torch expressions on any device ---
+GA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "area_rays.npz")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_area_sources_match_reference_run(tag):
+    """Fixture made by RUNNING area_source3_rand_bias / area_source3_cone with the host generator's draws recorded."""
+    from adjointnonlinearraytracing_amd import source
+    z = np.load(GA)
+    ang, p0, p1, spp, width, sd, circle, xaxis = z[f"bias_{tag}_args"].tolist()
+    kw = dict(circle=bool(circle), xaxis=bool(xaxis), sensor_dist=sd, device="cpu")
+    pix = (int(p0), int(p1))
+    (x, v, pl), xt, tpv = source.area_source3_rand_bias(torch.tensor(ang), pix, int(spp), width,
+                                                       offset=torch.from_numpy(z[f"bias_{tag}_uoff"]),
+                                                       tosense=torch.from_numpy(z[f"bias_{tag}_uts"]), **kw)
+    for got, key in ((x, "x"), (v, "v"), (pl, "planes"), (xt, "xt"), (tpv, "tpv")):
+        want = z[f"bias_{tag}_{key}"]
+        assert got.shape == want.shape and np.abs(got.numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), key
+    (x, v, pl), tpv = source.area_source3_cone(torch.tensor(ang), pix, int(spp), width, cone_angle=70.0,
+                                               offset=torch.from_numpy(z[f"cone_{tag}_uoff"]),
+                                               hatbox=torch.from_numpy(z[f"cone_{tag}_uhat"]), **kw)
+    for got, key in ((x, "x"), (v, "v"), (pl, "planes"), (tpv, "tpv")):
+        want = z[f"cone_{tag}_{key}"]
+        assert got.shape == want.shape, key       # (case b: the disc mask of the reference rejects every sample of the
+        if want.size:                             #  near-face source -- an empty ray set, reproduced as such)
+            assert np.abs(got.numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), key
+
+
+def test_area_view_collections_and_sum_norm():
+    from adjointnonlinearraytracing_amd import source
+    (x, v, pl), targets, dists, nrays = source.rand_area_in_sphere(3, (5, 4), 2, 1.0, angle_span=180, sensor_dist=0.3,
+                                                                   device="cpu")
+    assert nrays == [40, 40, 40] and x.shape == (120, 3) and pl.shape == (120, 3, 3) and targets.shape == (120, 3)
+    assert torch.allclose(v.norm(dim=1), torch.ones(120), atol=1e-5) and dists.shape == (120,)
+    (x, v, pl), dists, nrays = source.rand_cone_in_sphere(2, (4, 4), 3, 1.0, sensor_dist=0.0, cone_angle=60.0, device="cpu")
+    assert nrays == [48, 48] and torch.allclose(v.norm(dim=1), torch.ones(96), atol=1e-5)
+    im = torch.rand(6, 6) + 0.1
+    out, sc = source.sum_norm(im, scale=True)
+    assert abs(float(out.mean()) - 1.0) < 1e-6 and torch.allclose(out, source.sum_norm(im)) and float(sc) > 0
