@@ -201,13 +201,13 @@ def load_pmc():
 
 
 def pmc_kernel(pmc, *prefixes):
-    """First kernel of the PMC summary whose name starts with one of `prefixes` (in order of preference)."""
+    """The kernel of the PMC summary whose name starts with one of `prefixes` (in order of preference)."""
     if not pmc:
         return None
     for prefix in prefixes:
-        for k, v in pmc.items():
-            if k.startswith(prefix):
-                return v
+        hits = [v for k, v in pmc.items() if k.startswith(prefix)]
+        if hits:      # several instantiations may be launched (one returns at once): the one that did the work
+            return max(hits, key=lambda v: v.get("SQ_INSTS_VALU", 0.0))
     return None
 
 
