@@ -1235,6 +1235,21 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
 #define WIN_INDEX(cx, cy, cz) (DYN ? win_index_dyn(W, cx, cy, cz) : win_index(W.ox, W.oy, W.oz, cx, cy, cz))
     for (int it = 0; it < a.max_steps; ++it) {
       if (!__any(s.active)) break;                                              // wave-uniform exit
+#if defined(DRRT_PAD_VALU)
+      { float pa_ = 1.f, pb_ = 2.f, pc_ = 3.f, pd_ = 4.f;   // sensitivity experiment: 4 * DRRT_PAD_VALU extra v_fma per step
+#pragma unroll
+        for (int k_ = 0; k_ < DRRT_PAD_VALU; ++k_)
+          asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3"
+                       : "+v"(pa_), "+v"(pb_), "+v"(pc_), "+v"(pd_)); }
+#endif
+#if defined(DRRT_PAD_LDS)
+#pragma unroll
+      for (int k_ = 0; k_ < DRRT_PAD_LDS; ++k_) atomicAdd(win + 64 * k_ + lane, (win_t)0);   // conflict-free ds_add_f64 of 0.0
+#endif
+#if defined(DRRT_PAD_SALU)
+#pragma unroll
+      for (int k_ = 0; k_ < DRRT_PAD_SALU; ++k_) asm volatile("s_nop 0");
+#endif
       // ---- (re-)anchor the window around the cells the rays stand on (wave-uniform branch) ----
       const unsigned long long mm = __ballot(s.active & miss);
       if (mm != 0ull && cooldown == 0) {
