@@ -29,9 +29,12 @@ struct SensorArgs {
   float e_scalar;
   float p[3], n[3], t1[3], t2[3];
   int res; float span, inv_hs, half_span;
-  int far;                     // 1: generate_inf_sensor (coordinates from the direction only; span = 2*ang_cut)
+  int far;                     // 1: generate_inf_sensor (coordinates from the direction only; span = 2*ang_cut);
+                               // 2: get_sdf_vals_far (coordinates from the UN-normalised direction, sensor.py:134)
   float* image;                // forward out (res*res)
-  const float* grad_image;     // backward in
+  const float* grad_image;     // backward in (tex_get: the texture being sampled)
+  const float* grad_f;         // tex_get backward in: dL/df per ray
+  float* f_out;                // tex_get forward out: one value per ray
   float* grad_x; float* grad_v;
   size_t n_rays;
 };
@@ -47,7 +50,7 @@ __device__ __forceinline__ SensorRay sensor_locate(const SensorArgs& a, size_t i
   x[0] = a.x[3 * i]; x[1] = a.x[3 * i + 1]; x[2] = a.x[3 * i + 2];
   v[0] = a.v[3 * i]; v[1] = a.v[3 * i + 1]; v[2] = a.v[3 * i + 2];
   if (a.far) {                                                          // sensor.py:36-47
-    const float nv = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float nv = a.far == 2 ? 1.f : sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     const float inv = 1.f / nv;
     const float h0 = v[0] * inv, h1 = v[1] * inv, h2 = v[2] * inv;      // v / norm(v)
     const float xa = h0 * a.t1[0] + h1 * a.t1[1] + h2 * a.t1[2] + a.half_span;   // + ang_cut
@@ -213,6 +216,81 @@ __global__ void __launch_bounds__(256) k_sensor_splat_bwd(SensorArgs a) {
   a.grad_v[3 * i] = gv[0]; a.grad_v[3 * i + 1] = gv[1]; a.grad_v[3 * i + 2] = gv[2];
 }
 
+// ---- texture lookups at the sensor: core/sensor.py:102-138 get_sdf_vals_near / get_sdf_vals_far ---------------------
+// Grid(d_tex, h).Get(xn) (core/grid.py:100-124) at the rays' sensor coordinates: the same 4x4 radial tent taps as the
+// splat, used as an interpolant f = sum_i w_i f_i / sum_i w_i with tap indices CLIPPED to the texture (grid.py:57),
+// not masked (a point off the texture is extrapolated from the edge texels).  The backward is the interpolant's analytic derivative (what Get returns as its second value),
+// chained through the sensor frame and the plane intersection to (dL/dx, dL/dv).
+struct TexTaps { float W, fw, fda, fdb, sda, sdb; };
+// The taps follow the point (their texels are clipped, not the taps), so a point anywhere off the texture still has its
+// 16 taps around it -- unlike the splat, which drops rays that miss the image: re-derive the tap origin without that test.
+__device__ __forceinline__ void tex_origin(SensorRay& r) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float f = fminf(fmaxf(floorf(r.u[k]), -1048576.f), 1048576.f);     // NaN -> a bound; the weights are NaN/0 then
+    r.i1[k] = (int)f;
+  }
+  r.ok = true;
+}
+__device__ __forceinline__ TexTaps tex_taps(const SensorArgs& a, const SensorRay& r) {
+  TexTaps t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja) {
+    const int ia = r.i1[0] - 1 + ja;
+    const float da = r.u[0] - (float)ia;
+    const int ca = min(max(ia, 0), a.res - 1);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const int ib = r.i1[1] - 1 + jb;
+      const float db = r.u[1] - (float)ib;
+      const int cb = min(max(ib, 0), a.res - 1);
+      const float rr = sqrtf(da * da + db * db);
+      const float ww = fmaxf(1.41421356237f - rr, 0.f);
+      const float f = a.grad_image[(size_t)ca * a.res + cb];
+      const bool live = (ww > 0.f) & (rr > 0.f);
+      const float inv_r = live ? 1.f / rr : 0.f;
+      const float dwa = -da * inv_r, dwb = -db * inv_r;               // d w / d u
+      t.W += ww; t.fw += f * ww; t.fda += f * dwa; t.fdb += f * dwb; t.sda += dwa; t.sdb += dwb;
+    }
+  }
+  return t;
+}
+
+__global__ void __launch_bounds__(256) k_sensor_tex_get(SensorArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_rays) return;
+  float x[3], v[3];
+  SensorRay r = sensor_locate(a, i, x, v);
+  tex_origin(r);
+  const TexTaps t = tex_taps(a, r);
+  a.f_out[i] = t.fw / t.W;                                            // NaN coordinates: all weights 0 -> 0/0 = NaN
+}
+
+__global__ void __launch_bounds__(256) k_sensor_tex_get_bwd(SensorArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_rays) return;
+  float x[3], v[3];
+  SensorRay r = sensor_locate(a, i, x, v);
+  tex_origin(r);
+  float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f};
+  {
+    const TexTaps t = tex_taps(a, r);
+    const float f = t.fw / t.W;
+    const float k = a.grad_f[i] / t.W * a.inv_hs;
+    const float ga = k * (t.fda - f * t.sda), gb = k * (t.fdb - f * t.sdb);        // dL/d xn
+    const float gp0 = ga * a.t1[0] + gb * a.t2[0], gp1 = ga * a.t1[1] + gb * a.t2[1], gp2 = ga * a.t1[2] + gb * a.t2[2];
+    if (a.far) {                                    // far == 2: xn = v . T + ang_cut
+      gv[0] = gp0; gv[1] = gp1; gv[2] = gp2;
+    } else {
+      const float vg = (v[0] * gp0 + v[1] * gp1 + v[2] * gp2) / r.den;
+      gx[0] = gp0 - a.n[0] * vg; gx[1] = gp1 - a.n[1] * vg; gx[2] = gp2 - a.n[2] * vg;
+      gv[0] = r.t * gx[0]; gv[1] = r.t * gx[1]; gv[2] = r.t * gx[2];
+    }
+  }
+  a.grad_x[3 * i] = gx[0]; a.grad_x[3 * i + 1] = gx[1]; a.grad_x[3 * i + 2] = gx[2];
+  a.grad_v[3 * i] = gv[0]; a.grad_v[3 * i + 1] = gv[1]; a.grad_v[3 * i + 2] = gv[2];
+}
+
 int sensor_fail(int code, const char* msg);   // drrt_kernels.hip
 
 static int fill_args(SensorArgs& a, size_t n, const float* x, const float* v, const float* e, float e_scalar,
@@ -302,6 +380,47 @@ extern "C" int drrt_sensor_far_splat_bwd_f32(size_t n, const float* v, const flo
   if (n == 0) return DRRT_OK;
   a.grad_image = grad_image; a.grad_x = grad_x; a.grad_v = grad_v;
   hipLaunchKernelGGL(k_sensor_splat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+
+// ---- texture lookups at the sensor (core/sensor.py:102-138), see k_sensor_tex_get ------------------------------------
+// mode 0: get_sdf_vals_near (rays -> plane -> sensor frame, cell size span / res);
+// mode 1: get_sdf_vals_far  (coordinates v . T + ang_cut from the direction as it is, cell size 2 ang_cut / res; pass
+//         span = 2 * ang_cut).
+static int fill_tex(SensorArgs& a, size_t n, const float* x, const float* v, const float p[3], const float nrm[3],
+                    const float t1[3], const float t2[3], int res, float span, int mode, const float* tex) {
+  int rc = fill_args(a, n, x, v, nullptr, 1.f, p, nrm, t1, t2, res, span); if (rc) return rc;
+  if (!tex) return sensor_fail(DRRT_ERR_ARG, "null texture pointer");
+  if (mode != 0 && mode != 1) return sensor_fail(DRRT_ERR_ARG, "mode must be 0 (near) or 1 (far)");
+  a.far = mode == 1 ? 2 : 0;
+  a.grad_image = tex;
+  return DRRT_OK;
+}
+
+extern "C" int drrt_sensor_tex_get_f32(size_t n, const float* x, const float* v, const float plane_p[3],
+                                       const float plane_n[3], const float t1[3], const float t2[3], const float* tex,
+                                       int res, float span, int mode, float* f_out, void* stream) {
+  SensorArgs a{};
+  int rc = fill_tex(a, n, x, v, plane_p, plane_n, t1, t2, res, span, mode, tex); if (rc) return rc;
+  if (n == 0) return DRRT_OK;
+  if (!f_out) return sensor_fail(DRRT_ERR_ARG, "null output pointer");
+  a.f_out = f_out;
+  hipLaunchKernelGGL(k_sensor_tex_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+
+extern "C" int drrt_sensor_tex_get_bwd_f32(size_t n, const float* x, const float* v, const float plane_p[3],
+                                           const float plane_n[3], const float t1[3], const float t2[3],
+                                           const float* tex, int res, float span, int mode, const float* grad_f,
+                                           float* grad_x, float* grad_v, void* stream) {
+  SensorArgs a{};
+  int rc = fill_tex(a, n, x, v, plane_p, plane_n, t1, t2, res, span, mode, tex); if (rc) return rc;
+  if (n == 0) return DRRT_OK;
+  if (!grad_f || !grad_x || !grad_v) return sensor_fail(DRRT_ERR_ARG, "null gradient pointer");
+  a.grad_f = grad_f; a.grad_x = grad_x; a.grad_v = grad_v;
+  hipLaunchKernelGGL(k_sensor_tex_get_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   hipError_t le = hipGetLastError();
   return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
 }

@@ -4,6 +4,8 @@
 (``core/image_opt.py:99-101``, ``core/luneburg_opt.py:121-123``), and ``generate_inf_sensor`` (``:31-53``),
 the far-field (direction histogram) sensor of the image experiments (``core/image_opt.py:116``).
 
+``get_sdf_vals_near`` / ``get_sdf_vals_far`` (``:102-138``) sample a texture at the same sensor coordinates (fused kernels).
+
 ``generate_sensor`` keeps the reference's signature; on ``cuda`` (ROCm) tensors it runs the fused
 HIP kernels (``csrc/drrt_sensor.hip``: ray -> plane -> sensor frame -> 16 tent taps -> atomics, and
 the analytic backward that yields ``(grad_x, grad_v)`` directly) instead of ~20 (N,16)-sized torch
@@ -191,3 +193,60 @@ def generate_inf_sensor(rays, e, plane, res, angle_span=120, tangent=None):
     ang_cut = float(torch.sin(0.5 * torch.deg2rad(torch.tensor(float(angle_span), dtype=torch.float32))))   # :38
     t1, t2 = get_tan_vecs(n, tangent)
     return _FarSensorSplat.apply(v, e, t1, t2, res, ang_cut)
+
+
+class _TexGet(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, v, tex, p, n, t1, t2, span, mode):
+        if not x.is_cuda:
+            raise RuntimeError("get_sdf_vals_* expect tensors on the cuda (ROCm) device (no CPU path)")
+        dev = x.device
+        with torch.cuda.device(dev):
+            x_ = x.detach().to(torch.float32).contiguous()
+            v_ = v.detach().to(torch.float32).contiguous()
+            tex_ = tex.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if tex_.dim() != 2 or tex_.shape[0] != tex_.shape[1]:
+                raise RuntimeError("the texture must be square (the reference clips both axes with res[0])")
+            frame = (_vec3(p), _vec3(n), _vec3(t1), _vec3(t2))
+            f = torch.empty(x_.shape[0], dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().drrt_sensor_tex_get_f32(
+                x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()), *frame, C.c_void_p(tex_.data_ptr()),
+                int(tex_.shape[0]), float(span), int(mode), C.c_void_p(f.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.saved = (x_, v_, tex_, frame, float(span), int(mode))
+        return f
+
+    @staticmethod
+    def backward(ctx, grad_f):
+        x_, v_, tex_, frame, span, mode = ctx.saved
+        dev = x_.device
+        with torch.cuda.device(dev):
+            g = grad_f.detach().to(torch.float32).contiguous()
+            gx, gv = torch.empty_like(x_), torch.empty_like(v_)
+            _lib.check(_lib.load().drrt_sensor_tex_get_bwd_f32(
+                x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()), *frame, C.c_void_p(tex_.data_ptr()),
+                int(tex_.shape[0]), span, mode, C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()),
+                C.c_void_p(gv.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return gx, gv, None, None, None, None, None, None, None
+
+
+def get_sdf_vals_near(rays, d_tex, plane, span, tangent=None):
+    """core/sensor.py:102-119: the (res, res) texture ``d_tex`` (e.g. the signed distance to a measured caustic)
+    sampled at the points where the rays meet the sensor plane (Grid.Get's radial-tent interpolant); differentiable
+    w.r.t. the rays.  One fused HIP kernel each way (plane intersection, sensor frame, 16 taps)."""
+    x, v = rays
+    p, n = plane
+    t1, t2 = get_tan_vecs(n, tangent)
+    return _TexGet.apply(x, v, d_tex, p, n, t1, t2, span, 0)
+
+
+def get_sdf_vals_far(rays, d_tex, plane, ang_span, tangent=None):
+    """core/sensor.py:122-138: the texture sampled at the rays' directions projected on the sensor frame,
+    ``v . T + ang_cut`` with ``ang_cut = sin(ang_span / 2)`` (the direction as it is, not normalised -- as written)."""
+    x, v = rays
+    p, n = plane
+    ang_cut = float(torch.sin(0.5 * torch.deg2rad(torch.tensor(float(ang_span), dtype=torch.float32))))
+    t1, t2 = get_tan_vecs(n, tangent)
+    return _TexGet.apply(x, v, d_tex, p, n, t1, t2, 2.0 * ang_cut, 1)
+

@@ -299,6 +299,18 @@ DRRT_API int drrt_sensor_far_splat_bwd_f32(size_t n, const float* v, const float
                                   const float t2[3], int res, float ang_cut, const float* grad_image,
                                   float* grad_x, float* grad_v, void* stream);
 
+/* core/sensor.py:102-138 get_sdf_vals_near (mode 0) / get_sdf_vals_far (mode 1): Grid(tex, h).Get at the rays' sensor
+ * coordinates -- the 4x4 radial-tent interpolant of core/grid.py:100-124, tap indices clipped to the (res, res) texture
+ * (edge extrapolation off the texture, as in the reference) -- and its analytic backward w.r.t. the rays.  mode 0: rays ->
+ * plane -> sensor frame, cell size span / res; mode 1: coordinates v . T + span / 2 from the direction as it is (pass
+ * span = 2 * ang_cut).  tex, f_out, grad_f: device fp32; the plane and the tangents are host float[3].              */
+DRRT_API int drrt_sensor_tex_get_f32(size_t n, const float* x, const float* v, const float plane_p[3], const float plane_n[3],
+                            const float t1[3], const float t2[3], const float* tex, int res, float span, int mode,
+                            float* f_out, void* stream);
+DRRT_API int drrt_sensor_tex_get_bwd_f32(size_t n, const float* x, const float* v, const float plane_p[3],
+                                const float plane_n[3], const float t1[3], const float t2[3], const float* tex, int res,
+                                float span, int mode, const float* grad_f, float* grad_x, float* grad_v, void* stream);
+
 /* core/sensor.py:195-202 trace_rays_to_plane, the statement right after the march in every experiment: x_out = x + t v with
  * t = n.(p - x) / n.v (v passes through unchanged), and its analytic backward w.r.t. the rays (grad_x, grad_v receive the
  * part of the gradient that flows through x_out).  plane_stride 3 = one (p, n) per ray, 0 = one plane for all rays.

@@ -298,6 +298,33 @@ def rays_to_plane():
     save("rays_to_plane.npz", **out)
 
 
+def sdf_vals():
+    """core/sensor.py get_sdf_vals_near (:102-119) / get_sdf_vals_far (:122-138) and torch.autograd through them RUN AS IS
+    (float64, CPU); rays partly off the texture (edge extrapolation through the clipped tap indices)."""
+    torch.manual_seed(8)
+    out = {}
+    N, res, span = 700, 24, 2.0
+    tex = torch.randn(res, res, dtype=torch.float64).cumsum(0).cumsum(1) * 0.05
+    x = torch.rand(N, 3, dtype=torch.float64) * span * 1.3 - 0.15 * span
+    x[:, 1] = span * 0.9
+    v = torch.randn(N, 3, dtype=torch.float64) * 0.25
+    v[:, 1] = 1.0
+    p = torch.tensor([[span / 2, span * 1.1, span / 2]], dtype=torch.float64)
+    n = torch.tensor([[0.06, 1.0, -0.03]], dtype=torch.float64); n = n / n.norm()
+    t = torch.tensor([[0.0, 0.0, 1.0]], dtype=torch.float64)
+    for tag, fn, arg in (("near", ref_sensor.get_sdf_vals_near, span), ("far", ref_sensor.get_sdf_vals_far, 70.0)):
+        xx = x.clone().requires_grad_(True); vv = v.clone().requires_grad_(True)
+        f = fn((xx, vv), tex, (p, n), arg, t)
+        gf = torch.randn_like(f)
+        (f * gf).sum().backward()
+        gx = xx.grad if xx.grad is not None else torch.zeros_like(xx)        # far: the positions do not enter
+        out.update({f"{tag}_f": f.detach().numpy(), f"{tag}_gf": gf.numpy(), f"{tag}_gx": gx.numpy(),
+                    f"{tag}_gv": vv.grad.numpy(), f"{tag}_arg": np.asarray(arg)})
+    out.update({"x": x.numpy(), "v": v.numpy(), "p": p.numpy(), "n": n.numpy(), "t": t.numpy(), "tex": tex.numpy(),
+                "span": np.asarray(span)})
+    save("sdf_vals.npz", **out)
+
+
 def area_rays():
     """core/source.py area_source3_rand_bias (:107-150) and area_source3_cone (:152-183) RUN AS IS (float32, CPU); `*_u*`
     are the uniforms they drew: the host generator is re-seeded and the same torch.rand calls replayed."""
@@ -405,6 +432,7 @@ if __name__ == "__main__":
     sensor_splat()
     sensor_far()
     rays_to_plane()
+    sdf_vals()
     area_rays()
     cone_rays()
     upres()

@@ -245,3 +245,26 @@ def test_rays_to_plane_fused_matches_reference_run(gpu, tag):
     xo2, _ = sensor.trace_rays_to_plane((x.detach(), v.detach()), (p, f("n")))
     xo2.sum().backward()
     assert p.grad is not None and torch.allclose(xo2.detach(), xo.detach(), rtol=1e-5, atol=1e-6)
+
+
+# ---- get_sdf_vals_near / get_sdf_vals_far (core/sensor.py:102-138): texture lookups at the sensor --------------------
+GS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sdf_vals.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["near", "far"])
+def test_sdf_vals_match_reference_run(gpu, tag):
+    """Fixture made by RUNNING the reference's functions and autograd through them (float64); a third of the rays land
+    off the texture (edge extrapolation).  The fused kernels reproduce values and ray gradients to fp32 rounding."""
+    from adjointnonlinearraytracing_amd import sensor
+    z = np.load(GS)
+    f32 = lambda k: torch.from_numpy(z[k]).to(torch.float32).to(gpu)
+    x, v = f32("x").requires_grad_(True), f32("v").requires_grad_(True)
+    fn = sensor.get_sdf_vals_near if tag == "near" else sensor.get_sdf_vals_far
+    f = fn((x, v), f32("tex"), (f32("p"), f32("n")), float(z[f"{tag}_arg"]), f32("t"))
+    (f * f32(f"{tag}_gf")).sum().backward()
+    want = z[f"{tag}_f"]
+    assert np.abs(f.detach().cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
+    for got, key in ((x.grad, "gx"), (v.grad, "gv")):
+        w = z[f"{tag}_{key}"]
+        assert np.abs(got.cpu().numpy() - w).max() <= 2e-4 * max(np.abs(w).max(), 1e-30), key
