@@ -836,3 +836,53 @@ def test_fitted_windows_for_oblique_views(gpu):
         assert cases.rel_l2(grads["static"], grads["direct"]) <= 2e-6, ang
     assert fitted_waves[0.0] == 0, fitted_waves                       # dense axis-aligned bundles fit the default window
     assert fitted_waves[40.0] > 0, fitted_waves                       # the oblique view runs with fitted windows
+
+
+@pytest.mark.parametrize("ds_div", [2.0, 0.9])
+def test_fitted_windows_sweep(gpu, ds_div):
+    """Views at several angles about both axes, dense and sparse, half-cell and multi-cell steps, on a 48^3 grid: whatever
+    window variant the call picks, the gradient equals the one-atomic-per-tap kernel's (a wider sweep -- 126 cases on
+    48^3 / 96^3 / 130^3 grids, 122 of them with fitted windows -- was run once during development: worst 2.2e-7)."""
+    import ctypes as C
+    from adjointnonlinearraytracing_amd import _lib, source
+    lib = _lib.load()
+    R = 48
+    span = 1.0; h = span / (R - 1); ds = h / ds_div
+    g = torch.linspace(0.0, 1.0, R, device=gpu)
+    z, y, x = torch.meshgrid(g, g, g, indexing="ij")
+    rif = (1.0 + 0.08 * torch.exp(-((x - 0.45) ** 2 + (y - 0.55) ** 2 + (z - 0.5) ** 2) / 0.03)).contiguous()
+    nvox = rif.numel(); res = (C.c_int * 3)(R, R, R)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+    fitted = 0
+    for k, (ang, pix) in enumerate(((17.0, 24), (17.0, 96), (61.0, 48), (123.0, 24), (123.0, 48), (88.0, 96))):
+        xs, vs, _ = source.plane_source3_rand(torch.tensor(ang), (pix, pix), 2, span, xaxis=bool(k % 2),
+                                              sensor_dist=0.2 * span, device=gpu)
+        xs, vs = xs.contiguous(), vs.contiguous()
+        nr = xs.shape[0]
+        flags = _lib.FLAG_SORT_RAYS
+        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(nr, nvox, flags)), dtype=torch.uint8, device=gpu)
+        xt, vt = torch.empty_like(xs), torch.empty_like(vs)
+        st = torch.zeros(3, dtype=torch.int64, device=gpu)
+        _lib.check(lib.drrt_trace_f32(p(rif), nvox, res, nr, p(xs), p(vs), h, ds, p(xt), p(vt), p(st), p(ws), ws.numel(),
+                                      flags, stream))
+        cnt = C.c_size_t(0)
+        src = lib.drrt_last_order(C.byref(cnt))
+        torch.cuda.synchronize()
+        off = (src - ws.data_ptr()) // 4
+        order = ws.view(torch.int32)[off:off + nr].clone()
+        gen = torch.Generator().manual_seed(int(ang) + pix)
+        dx = torch.randn(nr, 3, generator=gen).to(gpu); dv = torch.randn(nr, 3, generator=gen).to(gpu)
+        grads = {}
+        for name, fl in (("auto", flags | _lib.FLAG_DEBUG_COUNTERS), ("direct", flags | _lib.FLAG_DIRECT_ATOMICS)):
+            grad = torch.empty(nvox, dtype=torch.float32, device=gpu)
+            lib.drrt_set_order_hint(p(order), nr)
+            _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, nr, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad), p(st),
+                                              p(ws), ws.numel(), fl, stream))
+            torch.cuda.synchronize()
+            grads[name] = grad.cpu().numpy().astype(np.float64)
+            if name == "auto":
+                o = (ws.numel() - 512) & ~7
+                fitted += int(ws[o:o + 512].view(torch.int64)[3]) > 0
+        assert cases.rel_l2(grads["auto"], grads["direct"]) <= 2e-6, (ang, pix)
+    assert fitted > 0
