@@ -5,6 +5,7 @@ the gradient mask/clamp all have to cooperate for that."""
 import os
 import sys
 
+import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
@@ -39,3 +40,24 @@ def test_tomography_loop_recovers_the_field(gpu):
     assert last < 0.5 * first, (first, last)
     assert err[-1] < 0.8 * err[0], (err[0], err[-1])
     assert float(n.min()) >= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sdf_weight", [0.0, 0.05])
+def test_image_experiment_flow(gpu, sdf_weight):
+    """examples/image_demo.py: the flow of core/image_opt.py on this package's mirrors -- area sources, near and
+    far-field sensor images, sum_norm, the optional SDF-texture term, multires_opt with the fused Adam tail: the
+    image loss must fall and the volume stay clamped.  (A design problem, not tomography: two views do not determine
+    the volume, so the distance to the hidden volume is reported by the demo but not asserted.)"""
+    import image_demo
+    from adjointnonlinearraytracing_amd import drrt
+    drrt.options.check_failed = False
+    n, truth, hist, err = image_demo.run(res_list=(9, 17), views=2, iters=25, nbins=24, sdf_weight=sdf_weight,
+                                         verbose=False)
+    assert drrt.options.corrected_h is False
+    assert n.shape == (17, 17, 17) and len(hist) == len(err) == 25 + 50
+    first, last = sum(hist[:3]) / 3, sum(hist[-3:]) / 3
+    # the images are Monte-Carlo estimates (16 samples per pixel): most of the MSE is their noise floor, the part the
+    # volume can explain falls by about a tenth of the total here (seeded: 0.0303 -> 0.0274)
+    assert np.isfinite(hist).all() and last < 0.96 * first, (first, last)
+    assert float(n.min()) >= 1.0 and float(n.max()) > 1.005
