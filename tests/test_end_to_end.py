@@ -61,3 +61,17 @@ def test_image_experiment_flow(gpu, sdf_weight):
     # volume can explain falls by about a tenth of the total here (seeded: 0.0303 -> 0.0274)
     assert np.isfinite(hist).all() and last < 0.96 * first, (first, last)
     assert float(n.min()) >= 1.0 and float(n.max()) > 1.005
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src", ["cone", "planar"])
+def test_fibre_experiment_flow(gpu, src):
+    """examples/fiber_demo.py: the flow of core/fiber_opt.py -- cone / plane source, boundary index through
+    cable.Cable.GetLinear, tracer.BackCableTracerC towards two targets a hop apart, Adam on the radial profile with the
+    experiment's midpoint up-sampling: the refocusing loss must fall by a large factor."""
+    import fiber_demo
+    n, hist = fiber_demo.run(res_list=(5, 9), iters=20, nbins=24, src_type=src, verbose=False)
+    assert n.shape == (9,) and len(hist) == 20 + 40 and np.isfinite(hist).all()
+    first, last = sum(hist[:3]) / 3, sum(hist[-3:]) / 3
+    assert last < 0.5 * first, (first, last)
+    assert abs(float(n[-1]) - 1.0) < 1e-6                                # the cladding sample is never updated (:240)
