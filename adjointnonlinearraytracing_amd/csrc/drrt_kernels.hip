@@ -629,7 +629,7 @@ typedef double win_t;
 constexpr int kWinX = DRRT_WIN, kWinY = DRRT_WIN, kWinZ = DRRT_WIN;
 constexpr int kWinPX = DRRT_WIN + DRRT_WIN_PAD;           // row pitch
 constexpr int kWinSY = kWinPX, kWinSZ = kWinPX * kWinY;   // LDS strides of y and z
-constexpr int kWinFloats = kWinSZ * kWinZ;                // 1100 slots = 8.6 KiB per wave
+constexpr int kWinFloats = kWinSZ * kWinZ;                // 810 slots = 6.3 KiB per wave (9^3 window, pitch 10)
 constexpr int kWavesPerBlock = kBlock / kWave;
 
 __device__ __forceinline__ void wave_lds_fence() {
