@@ -603,10 +603,12 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
 // grid -- one fp32 atomic per touched voxel, contiguous in x -- only when the rays walk out of it.  Lanes whose cell falls outside the window (incoherent wave, clamped
 // boundary cell) fall back to direct global atomics, so the result never depends on the window.
 //
-//   window      kWinX x kWinY x kWinZ voxels of double accumulators, row pitch kWinPX (measured:
-//               edge 10 beats 8 and 12; padding the pitch or not is within 1 %)
+//   window      kWinX x kWinY x kWinZ voxels of double accumulators, row pitch kWinPX (measured, final
+//               kernels: edge 9 beats 7, 8, 10, 12; padding the pitch or not is within 1 %); the flat
+//               kernel can also size the window to the wave's rays at run time (WinDyn)
 //   ablations   BackArgs::experiment (bits 8..15 of `flags`, development only): 1 = no accumulation
-//               at all, 2 = no global atomics, 3 = no LDS adds
+//               at all, 2 = no global atomics, 3 = no LDS adds, 4 = hand over all 8 corners on every
+//               leave, 5 = never flush, 6 = no DPP pre-reduction, 7 = never fit the window
 //   anchor      around the cell of the wave's median contributing lane, shifted towards its
 //               direction of travel (most of the window lies ahead of the rays)
 //   re-anchor   as soon as a contributing lane misses the window (wave-uniform decision); if lanes
