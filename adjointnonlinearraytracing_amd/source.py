@@ -22,8 +22,9 @@ and ``sum_norm`` (``:415-420``) are the reference's element-wise torch expressio
 no gather and no batched matmul, so there is nothing for a hand-written kernel to win); their keyword-only ``offset`` /
 ``tosense`` / ``hatbox`` arguments take the uniform draws, so the reference's draws reproduce its rays.
 
-The deterministic point source (``:29-51``) is not provided: ``rand_rays_cube`` with ``src_type == 'point'`` raises
-``NotImplementedError``.
+The deterministic point source ``point_source3`` (``:29-51``, also ``rand_rays_cube(src_type='point')``) is likewise a
+handful of torch expressions on the chosen device; it draws nothing, so a run of the reference pins it outright
+(``tests/golden/point_rays.npz``).
 """
 from __future__ import annotations
 
@@ -160,15 +161,40 @@ def rand_ptcone_in_sphere(nviews, im_res, spp, width, angle_span=360, circle=Fal
     return iv, torch.zeros(nviews), nrays
 
 
+def point_source3(angle, pixels, spp, width, cone_angle=90, xaxis=False, sensor_dist=0.0, circle=False, *, device=None):
+    """core/source.py:29-51 -> (x, v, planes): the deterministic point source. One ray per node of a
+    (pixels[0]*s) x (pixels[1]*s) lattice of (theta, phi) in [-cone_angle/2, cone_angle/2], s = max(floor(sqrt(spp)), 1),
+    all leaving (0, -width/2, 0) rotated into the view; `circle` is accepted and unused, as there.
+    Plain torch on `device` (default: cpu, like the reference) -- a few elementwise ops, not worth a kernel."""
+    dev = torch.device("cpu" if device is None else device)
+    half = float(np.radians(cone_angle / 2))
+    s = max(int(np.floor(np.sqrt(spp))), 1)
+    axes = [torch.linspace(-half, half, int(p) * s, device=dev) for p in pixels]
+    theta, phi = torch.meshgrid(axes, indexing="ij")
+    theta, phi = theta.flatten(), phi.flatten()
+    vel = torch.stack([torch.cos(theta) * torch.sin(phi), torch.cos(theta) * torch.cos(phi), torch.sin(theta)], dim=-1)
+    vel = vel / torch.norm(vel, dim=-1, keepdim=True)
+    n = theta.shape[0]
+    pos = torch.tensor([[0.0, -width / 2, 0.0]], device=dev).repeat(n, 1)
+    x = rotate_ray3(pos, angle, vert=xaxis) + width / 2
+    v = rotate_ray3(vel, angle, vert=xaxis)
+    return x, v, _planes_of_view(n, angle, xaxis, width, sensor_dist, dev)
+
+
 def rand_rays_cube(im_res, spp, width, circle=False, src_type='plane', cone_ang=90,
                    *, offset=None, device=None, rotmat=None, span=None):
     """core/source.py:398-412 -> ((x, v, planes), nrays): four views about z, two about x, sensor_dist = 0.
-    src_type 'plane' (plane_source3_rand) or anything but 'point' (cone_source3_rand with cone_angle = cone_ang, :402-404);
-    'point' selects the reference's deterministic point_source3, which is not on the device path."""
-    if src_type == 'point':
-        raise NotImplementedError("point_source3 (deterministic point source, core/source.py:401) is not generated on the device")
+    src_type 'plane' (plane_source3_rand), 'point' (the deterministic point_source3 with cone_angle = cone_ang, :401) or
+    anything else (cone_source3_rand with cone_angle = cone_ang, :402-404)."""
     angles = torch.linspace(0, 360, 5)
     vangles = torch.tensor([90, -90])
+    if src_type == 'point':
+        dev = torch.device("cuda" if device is None else device)
+        views = [point_source3(angles[i], im_res, spp, width, cone_angle=cone_ang, xaxis=False, device=dev)
+                 for i in range(len(angles) - 1)]
+        views += [point_source3(va, im_res, spp, width, cone_angle=cone_ang, xaxis=True, device=dev) for va in vangles]
+        nrays = [vw[0].shape[0] for vw in views]
+        return tuple(map(torch.cat, zip(*views))), nrays
     mats = [_view_matrix(angles[i], False) for i in range(len(angles) - 1)]
     mats += [_view_matrix(va, True) for va in vangles]
     if src_type != 'plane':

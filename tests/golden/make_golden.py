@@ -351,6 +351,20 @@ def area_rays():
     save("area_rays.npz", **out)
 
 
+def point_rays():
+    """core/source.py point_source3 (:29-51) and rand_rays_cube(src_type='point') (:398-412) RUN AS IS (float32, CPU);
+    deterministic, so the arrays are the whole fixture."""
+    out = {}
+    for tag, ang, pix, spp, width, cone, xaxis, sd in (("a", 40.0, (5, 4), 4, 2.0, 60.0, False, 0.0),
+                                                       ("b", -115.0, (3, 6), 3, 1.5, 90.0, True, 0.25)):
+        x, v, pl = ref_source.point_source3(torch.tensor(ang), pix, spp, width, cone_angle=cone, xaxis=xaxis, sensor_dist=sd)
+        out.update({f"{tag}_x": x.numpy(), f"{tag}_v": v.numpy(), f"{tag}_planes": pl.numpy(),
+                    f"{tag}_args": np.array([ang, pix[0], pix[1], spp, width, cone, float(xaxis), sd])})
+    (x, v, pl), nrays = ref_source.rand_rays_cube((4, 3), 4, 1.0, src_type='point', cone_ang=50)
+    out.update({"cube_x": x.numpy(), "cube_v": v.numpy(), "cube_planes": pl.numpy(), "cube_nrays": np.array(nrays)})
+    save("point_rays.npz", **out)
+
+
 def source_rays():
     """core/source.py generators RUN AS IS; `u_*` are the uniforms they drew (same seed replayed)."""
     out = {}
@@ -434,6 +448,7 @@ if __name__ == "__main__":
     rays_to_plane()
     sdf_vals()
     area_rays()
+    point_rays()
     cone_rays()
     upres()
     source_rays()

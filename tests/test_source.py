@@ -180,8 +180,6 @@ def test_hip_generated_rays_feed_the_march(S):
 @pytest.mark.gpu
 def test_hip_source_argument_errors(S):
     import torch
-    with pytest.raises(NotImplementedError):
-        S.rand_rays_cube((8, 8), 1, 1.0, src_type="point")
     with pytest.raises(RuntimeError):
         S.rand_rays_cube((8, 8), 1, -1.0)
     with pytest.raises(RuntimeError):
@@ -220,8 +218,10 @@ def test_hip_cone_source_matches_reference_run(gpu, cone_gold, S):
     (x, v, pl), nr = S.rand_rays_cube(pix, spp, width, src_type='cone', cone_ang=60, offset=torch.from_numpy(g["cube_u"]), device=gpu)
     assert nr == g["cube_nrays"].tolist()
     _close(_np(x), g["cube_x"], ulps(width)); _close(_np(v), g["cube_v"], 4 * ulps(1.0)); _close(_np(pl), g["cube_planes"], ulps(width))
-    with pytest.raises(NotImplementedError):
-        S.rand_rays_cube(pix, spp, width, src_type='point', device=gpu)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "point_rays.npz"))
+    (x, v, pl), nr = S.rand_rays_cube((4, 3), 4, 1.0, src_type='point', cone_ang=50, device=gpu)   # torch ops on the device
+    assert nr == z["cube_nrays"].tolist() and x.is_cuda
+    _close(_np(x), z["cube_x"], 4 * ulps(1.0)); _close(_np(v), z["cube_v"], 8 * ulps(1.0)); _close(_np(pl), z["cube_planes"], 4 * ulps(1.0))
 
 
 @pytest.mark.gpu
@@ -280,3 +280,24 @@ def test_area_view_collections_and_sum_norm():
     im = torch.rand(6, 6) + 0.1
     out, sc = source.sum_norm(im, scale=True)
     assert abs(float(out.mean()) - 1.0) < 1e-6 and torch.allclose(out, source.sum_norm(im)) and float(sc) > 0
+
+
+GP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "point_rays.npz")
+
+
+def test_point_source_matches_reference_run():
+    """Fixture made by RUNNING point_source3 / rand_rays_cube(src_type='point') (deterministic): same torch ops on the
+    CPU, so the match is exact up to the last place of the rotation matmul."""
+    from adjointnonlinearraytracing_amd import source
+    z = np.load(GP)
+    for tag in ("a", "b"):
+        ang, p0, p1, spp, width, cone, xaxis, sd = z[f"{tag}_args"].tolist()
+        x, v, pl = source.point_source3(torch.tensor(ang), (int(p0), int(p1)), int(spp), width, cone_angle=cone,
+                                        xaxis=bool(xaxis), sensor_dist=sd)
+        for got, key in ((x, "x"), (v, "v"), (pl, "planes")):
+            want = z[f"{tag}_{key}"]
+            assert got.shape == want.shape and np.abs(got.numpy() - want).max() <= 1e-6, key
+    (x, v, pl), nrays = source.rand_rays_cube((4, 3), 4, 1.0, src_type='point', cone_ang=50, device="cpu")
+    assert nrays == z["cube_nrays"].tolist()
+    for got, key in ((x, "x"), (v, "v"), (pl, "planes")):
+        assert np.abs(got.numpy() - z[f"cube_{key}"]).max() <= 1e-6, key
