@@ -1231,6 +1231,10 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
   int cooldown = 0;
   unsigned steps = 0;
   unsigned n_flush = 0;
+  // event counters of the debug instantiation (a.dbg): [4] one-face leaves handed to the window, [5] of those, lanes that
+  // issued the LDS adds after the pair / quad pre-reduction, [6] one-face leaves that went to global atomics (cell outside
+  // the window), [7] leaves that handed over all eight corners, [8] wave-steps, [9] wave-steps with leaves across >= 2 axes
+  unsigned ev_face = 0, ev_add = 0, ev_glob = 0, ev_all8 = 0, ev_wsteps = 0, ev_multi = 0;
 
 #define WSY (DYN ? W.sy : kWinSY)
 #define WSZ (DYN ? W.sz : kWinSZ)
@@ -1372,6 +1376,10 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
                   if (regular & (ax | ay | az) & (experiment != 1) & (experiment != 4)) {
                     // one face crossed: emit the face left behind, carry the shared one
                     const bool fwd = d > 0;
+                    if (ABL && a.dbg) {
+                      const int nax = (__ballot(ax) != 0ull) + (__ballot(ay) != 0ull) + (__ballot(az) != 0ull);
+                      if (lane == __ffsll((long long)__ballot(true)) - 1) ev_multi += nax >= 2;
+                    }
                     // emitted corners e0..e3 and carried ones, in (p, q) in-face order; LDS / grid strides of p, q and of the axis
                     float e0, e1, e2, e3;
                     int lp, lq, la, gp, gq, ga;
@@ -1416,6 +1424,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
                         const float s3 = q3 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q3), 0x4E, 0xF, 0xF, false));
                         const unsigned ql = threadIdx.x & 3u;
                         const bool add = same ? ql == 0u : (psame ? (ql & 1u) == 0u : true);
+                        if (ABL) { ++ev_face; ev_add += add; }
                         if (experiment == 6) {            // ablation: no pre-reduction, every lane adds its own values
                           win_t* q = win + qi;
                           atomicAdd(q, (win_t)e0); atomicAdd(q + lp, (win_t)e1); atomicAdd(q + lq, (win_t)e2); atomicAdd(q + lq + lp, (win_t)e3);
@@ -1427,11 +1436,13 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
                       }
                       used_lds = experiment != 5;         // ablation 5: never flush (until the end)
                     } else if (experiment != 2) {
+                      if (ABL) ++ev_glob;
                       float* g = a.grad + old_base + (fwd ? 0 : ga);
                       atomic_add_f32(g, e0); atomic_add_f32(g + gp, e1); atomic_add_f32(g + gq, e2); atomic_add_f32(g + gq + gp, e3);
                     }
                   } else {
                     // jump over more than one face, or into a clamped cell: hand over all eight
+                    if (ABL) ++ev_all8;
                     if (experiment != 1) used_lds = flat_emit8(win, WSY, WSZ, a.grad, V.sy, V.sz, old_lidx, old_base, p00, p10, p01, p11);
                     p00 = p10 = p01 = p11 = f2{0.f, 0.f};
                   }
@@ -1444,6 +1455,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
         }
       }
       dirty = dirty | (__ballot(used_lds) != 0ull);
+      if (ABL) ev_wsteps += lane == 0;
     }
 #undef WSY
 #undef WSZ
@@ -1459,6 +1471,12 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
   if (ABL && a.dbg) {
     if (lane == 0) atomicAdd(&a.dbg[0], (unsigned long long)n_flush);
     if (DYN && lane == 0) atomicAdd(&a.dbg[3], 1ull);          // waves that ran with run-time window dimensions
+    if (ev_face) atomicAdd(&a.dbg[4], (unsigned long long)ev_face);
+    if (ev_add) atomicAdd(&a.dbg[5], (unsigned long long)ev_add);
+    if (ev_glob) atomicAdd(&a.dbg[6], (unsigned long long)ev_glob);
+    if (ev_all8) atomicAdd(&a.dbg[7], (unsigned long long)ev_all8);
+    if (ev_wsteps) atomicAdd(&a.dbg[8], (unsigned long long)ev_wsteps);
+    if (ev_multi) atomicAdd(&a.dbg[9], (unsigned long long)ev_multi);
   }
   block_stats(a.stats, steps, 0u);
 }

@@ -405,7 +405,9 @@ def run_rank(args) -> int:
         if args.debug_counters:
             off = (ws.numel() - 512) & ~7
             dbg = ws[off:off + 512].view(torch.int64).cpu().tolist()
-            print(f"[debug] window flushes {dbg[0]}, ray-steps via LDS window {dbg[1]}, via global fallback {dbg[2]}",
+            print(f"[debug] window flushes {dbg[0]}, ray-steps via LDS window {dbg[1]}, via global fallback {dbg[2]}, "
+                  f"fitted waves {dbg[3]}; leaves: one face -> window {dbg[4]} (lanes adding after pre-reduction {dbg[5]}), "
+                  f"one face -> global {dbg[6]}, all eight {dbg[7]}; wave-steps {dbg[8]}, with >= 2 axes leaving {dbg[9]}",
                   file=sys.stderr)
         fwd_steps = int(st_f[0].item()); adj_steps = int(st_a[0].item())
         n_failed = int(st_f[1].item())

@@ -94,7 +94,13 @@ extern "C" {
                                        [0] LDS-window flushes, [1] ray-steps accumulated through
                                        the LDS window, [2] ray-steps that fell back to global atomics
                                        ([1], [2]: round-1 kernel only), [3] waves that ran with
-                                       run-time window dimensions (fitted windows).
+                                       run-time window dimensions (fitted windows);
+                                       k_backtrace_flat events: [4] one-face cell leaves handed to the
+                                       window, [5] lanes of those that issued the LDS adds after the
+                                       pair / quad pre-reduction, [6] one-face leaves sent to global
+                                       atomics (cell outside the window), [7] leaves that handed over
+                                       all eight corners, [8] wave-steps, [9] wave-steps whose one-face
+                                       leaves cross two or three different axes.
                                        Bits 8..15 of `flags` select development ablations (0 = product) */
 
 /* Limits (violations are refused with DRRT_ERR_ARG and a message, never truncated silently):
