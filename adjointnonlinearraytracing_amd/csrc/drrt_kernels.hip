@@ -244,10 +244,18 @@ __device__ __forceinline__ void flat_begin(const Vol& V, const TapRows& R, FlatR
   if (r.interior) gather_rows<PAIR>(R, r.off, r.q0, r.q1);
 }
 
+// trace_plane (MODE 1): the sensor plane of the ray; "inside" additionally means "not past the plane" (:144-145)
+struct FlatPlane { float ox, oy, oz, dx, dy, dz; };
+__device__ __forceinline__ bool flat_past_plane(const FlatPlane& P, const FlatRay& r) {
+  return dot3(r.x - P.ox, r.y - P.oy, r.z - P.oz, P.dx, P.dy, P.dz) > 0.f;
+}
+
 // The box tests of a ray that has just stepped into a boundary cell (:73-76, :86): may end the ray.
-__device__ __forceinline__ void flat_boundary(const Vol& V, int it, FlatRay& r) {
-  const bool cur_inside = inbounds(V, r.x, r.y, r.z);                                       // :73
+template <int MODE>
+__device__ __forceinline__ void flat_boundary(const Vol& V, const FlatPlane& P, int it, FlatRay& r) {
+  bool cur_inside = inbounds(V, r.x, r.y, r.z);                                             // :73
   const bool esc_now = escaped(V, r.x, r.y, r.z, r.vx, r.vy, r.vz);                         // :76
+  if (MODE == 1) cur_inside = cur_inside & !flat_past_plane(P, r);                          // :144-145
   const bool cross = r.inside & !cur_inside;                                                // :74
   r.inside = cur_inside;                                                                    // :86
   if (cross | esc_now) { r.crossed = cross; r.live = false; r.steps = (unsigned)it + 1u; }  // :75-76
@@ -258,8 +266,8 @@ __device__ __forceinline__ void flat_boundary(const Vol& V, int it, FlatRay& r) 
 // In-place locate(): the floor index by one conversion; the fractions by v_fract, == f - floor(f) bit for bit for the
 // non-negative coordinates of an interior cell.  The fractions (and clamp offsets) of a BOUNDARY cell are not
 // carried: they are re-derived by locate() when such a cell is sampled.
-template <bool PAIR>
-__device__ __forceinline__ bool flat_advance(const Vol& V, float ds, int it, FlatRay& r) {
+template <bool PAIR, int MODE>
+__device__ __forceinline__ bool flat_advance(const Vol& V, const FlatPlane& P, float ds, int it, FlatRay& r) {
   if (r.inside) {                                                                           // masked gather (Q4)
     if (!r.interior) {                            // boundary cell: clamp offsets and fractions from the position, taps fetched here
       const Cell cb = locate(V, r.x, r.y, r.z);
@@ -280,15 +288,24 @@ __device__ __forceinline__ bool flat_advance(const Vol& V, float ds, int it, Fla
     // strictly interior: in bounds, not escaped, nothing to record (Cell::interior) -- sample weights and taps only
     r.wx = __builtin_amdgcn_fractf(fx); r.wy = __builtin_amdgcn_fractf(fy); r.wz = __builtin_amdgcn_fractf(fz);
     const unsigned noff = tap_offset<PAIR>(mad24(iz, V.sz, mad24(iy, V.sy, ix)));
-    r.inside = true;                                                                        // :73, :86
+    if (MODE == 1) {                                                                        // the plane is the only test left
+      const bool past = flat_past_plane(P, r);
+      if (r.inside & past) { r.crossed = true; r.live = false; r.steps = (unsigned)it + 1u; }   // :74-75
+      r.inside = !past;                                                                     // :86
+    } else {
+      r.inside = true;                                                                      // :73, :86
+    }
     if (!(was_interior & (noff == r.off))) { r.off = noff; return true; }
   } else {
-    flat_boundary(V, it, r);
+    flat_boundary<MODE>(V, P, it, r);
   }
   return false;
 }
 
-template <bool PAIR>   // PAIR: gather from the pair copy of the grid (two 16-byte loads per cell, see gather_rows)
+// PAIR: gather from the pair copy of the grid (two 16-byte loads per cell, see gather_rows).  MODE 0 = trace, 1 = trace_plane
+// (same march; the ray also ends when it passes its sensor plane, and rays that could produce a later exit record in the
+// reference's global loop are flagged for k_trace_again exactly as k_trace<1> does, see plane_again).
+template <bool PAIR, int MODE>
 __global__ void __launch_bounds__(kBlock) k_trace_flat(TraceArgs a) {
   const Vol& V = a.vol;
   const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -297,12 +314,17 @@ __global__ void __launch_bounds__(kBlock) k_trace_flat(TraceArgs a) {
   size_t i;
   if (ray_index(a.perm, t, a.n, i)) {
     FlatRay r;
+    FlatPlane P{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {
       const Ray3 p = ld3(a.pos, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vel, i, a.io_half, &a.vol, RAY_VEL);
       flat_begin<PAIR>(V, R, r, p, u);
+      if (MODE == 1) {
+        const Ray3 o = ld3(a.pln_o, i), d = ld3(a.pln_d, i);
+        P.ox = o.x; P.oy = o.y; P.oz = o.z; P.dx = d.x; P.dy = d.y; P.dz = d.z;
+      }
     }
     for (int it = 0; it < a.max_steps; ++it) {
-      if (flat_advance<PAIR>(V, a.ds, it, r)) gather_rows<PAIR>(R, r.off, r.q0, r.q1);
+      if (flat_advance<PAIR, MODE>(V, P, a.ds, it, r)) gather_rows<PAIR>(R, r.off, r.q0, r.q1);
       if (!r.live) break;
     }
     const bool esc = !r.live;
@@ -318,6 +340,15 @@ __global__ void __launch_bounds__(kBlock) k_trace_flat(TraceArgs a) {
     }
     st3(a.xt, i, xtx, xty, xtz, a.io_half, &a.vol, RAY_POS);
     st3(a.vt, i, vtx, vty, vtz, a.io_half, &a.vol, RAY_VEL);
+    if (MODE == 1) {
+      bool again = false;
+      if (esc) {                                                                           // plane_again() on the final state
+        const float d = dot3(r.x - P.ox, r.y - P.oy, r.z - P.oz, P.dx, P.dy, P.dz);
+        const float dv = dot3(r.vx, r.vy, r.vz, P.dx, P.dy, P.dz);
+        again = !(escaped(V, r.x, r.y, r.z, r.vx, r.vy, r.vz) | ((d > 0.f) & (dv >= 0.f)));
+      }
+      a.failmask[i] = (esc ? 0 : 1) | (again ? 2 : 0);                                     // src/tracer.cpp:171; bit 1: k_trace_again
+    }
   }
   block_stats(a.stats, steps, failed);
 }
@@ -1158,7 +1189,9 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
 //       (WinDyn); DYN = false is the kernel with compile-time window strides.  When the call has a visit order the host
 //       launches BOTH and each instance returns at once unless a.select picks it (k_bundle_classify decides on the
 //       device, from how the 64-ray bundles sit at their start, without a host round trip).
-template <bool ABL, bool PAIR, bool DYN>
+// MODE: 0 = backtrace, 1 = backtrace_sdf (the ray also ends where the sdf sample turns non-negative, :488-497; the sdf
+//       taps are a second, un-pipelined gather per step).
+template <bool ABL, bool PAIR, bool DYN, int MODE = 0>
 __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackArgs a) {
   if (a.select != nullptr) {
     const bool want_dyn = a.select[0] * 8u >= a.select[1] && a.select[0] != 0u;     // >= 1/8 of the waves would gain
@@ -1181,6 +1214,10 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
     Ray3 p = ld3(a.xt, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vt, i, a.io_half, &a.vol, RAY_VEL), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
     s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
     adj_init(V, a.ds, gxv.x, gxv.y, gxv.z, gvv.x, gvv.y, gvv.z, s);
+    if (MODE == 1 && s.active) {                                            // src/tracer.cpp:476-477
+      const Cell c0 = locate(V, s.x, s.y, s.z);
+      s.outside = interp<false>(fetch(a.sdf, c0), c0.wx, c0.wy, c0.wz).n >= 0.f;
+    }
   }
   const int experiment = ABL ? a.experiment : 0;
   WinDyn W;                                                    // the wave's window (wave-uniform)
@@ -1328,9 +1365,13 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
         Cell c;                                              // what adj_sample reads of the cell: fractions, interior
         c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0;
         c.wx = wx; c.wy = wy; c.wz = wz; c.interior = interior;
+        if (MODE == 1) {                                     // adj_sample<1> gathers the sdf taps of this cell itself
+          if (interior) { c.base = base; c.ox = 1; c.oy = V.sy; c.oz = V.sz; }
+          else c = locate(V, s.x, s.y, s.z);
+        }
         const float px = s.x, py = s.y, pz = s.z;            // position of this sample (the clamped splat re-locates it)
         AdjSample m;
-        if (!adj_sample<0>(V, nullptr, a.ds, s, c, taps_of<PAIR>(q0, q1), m)) {
+        if (!adj_sample<MODE>(V, a.sdf, a.ds, s, c, taps_of<PAIR>(q0, q1), m)) {
           // the ray has ended (:426-428): it contributes nothing here; hand over what its cell has accumulated
           if (regular && experiment != 1) used_lds = flat_emit8(win, WSY, WSZ, a.grad, V.sy, V.sz, lidx, base, p00, p10, p01, p11);
         } else {
@@ -1837,9 +1878,10 @@ static int run_trace(const float* rif, const float* sdf, long long nvox, const i
     ProfScope prof(DRRT_PROF_TRACE, s);
     if (MODE == 2 || !(flags & DRRT_FLAG_LDS_BRICKS)) {
       const unsigned reuse = (flags & DRRT_FLAG_TAP_REUSE_MASK);
-      if (MODE == 0 && reuse == 0 && !(flags & DRRT_FLAG_LEGACY_FORWARD)) {
-        if (a.vol.pair != nullptr) hipLaunchKernelGGL(k_trace_flat<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
-        else                       hipLaunchKernelGGL(k_trace_flat<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+      if ((MODE == 0 || MODE == 1) && reuse == 0 && !(flags & DRRT_FLAG_LEGACY_FORWARD)) {
+        constexpr int FM = MODE == 1 ? 1 : 0;
+        if (a.vol.pair != nullptr) hipLaunchKernelGGL((k_trace_flat<true, FM>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+        else                       hipLaunchKernelGGL((k_trace_flat<false, FM>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
       }
       else if (reuse == DRRT_FLAG_TAP_REUSE_OFF)
         hipLaunchKernelGGL((k_trace<MODE, 0>), dim3(grid_for(n)), dim3(kBlock), 0, s, a);
@@ -2029,7 +2071,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
     ProfScope prof(DRRT_PROF_BACKTRACE, s);
     if (flags & DRRT_FLAG_DIRECT_ATOMICS)
       hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
-    else if (MODE == 0 && !(flags & DRRT_FLAG_LEGACY_ADJOINT)) {
+    else if (!(flags & DRRT_FLAG_LEGACY_ADJOINT)) {
       const bool abl = a.experiment != 0 || a.dbg != nullptr, pair = a.vol.pair != nullptr;
       const dim3 g(grid_for(n));
       // With a visit order the bundles are classified on the device and BOTH window variants are launched; the one the
@@ -2045,10 +2087,13 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
       }
 #define DRRT_LAUNCH_FLAT(DYN)                                                                                         \
       do {                                                                                                            \
-        if (abl) { if (pair) hipLaunchKernelGGL((k_backtrace_flat<true, true, DYN>), g, dim3(kBlock), 0, s, a);       \
-                   else      hipLaunchKernelGGL((k_backtrace_flat<true, false, DYN>), g, dim3(kBlock), 0, s, a); }    \
-        else     { if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true, DYN>), g, dim3(kBlock), 0, s, a);      \
-                   else      hipLaunchKernelGGL((k_backtrace_flat<false, false, DYN>), g, dim3(kBlock), 0, s, a); }   \
+        if (abl && MODE == 0) {                                                                                       \
+          if (pair) hipLaunchKernelGGL((k_backtrace_flat<true, true, DYN, 0>), g, dim3(kBlock), 0, s, a);             \
+          else      hipLaunchKernelGGL((k_backtrace_flat<true, false, DYN, 0>), g, dim3(kBlock), 0, s, a);            \
+        } else {    /* the ablation / counter instantiation exists for backtrace only */                              \
+          if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true, DYN, MODE>), g, dim3(kBlock), 0, s, a);         \
+          else      hipLaunchKernelGGL((k_backtrace_flat<false, false, DYN, MODE>), g, dim3(kBlock), 0, s, a);        \
+        }                                                                                                             \
       } while (0)
       DRRT_LAUNCH_FLAT(false);
       if (a.select != nullptr) DRRT_LAUNCH_FLAT(true);

@@ -263,11 +263,16 @@ def test_trace_plane_and_target(gpu, oracle, drrt_mod):
     pd = np.tile(np.array([[0, 1, 0]], np.float32), (len(pos), 1))
     drrt_mod.options.sort_rays = True
     T = drrt_mod.TracerC()
-    xt, vt, fm = T.trace_pln(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), _t(po, gpu), _t(pd, gpu), h, ds)
     with oracle.arith("factored"):
         ref = oracle.trace(rif, rif.shape, pos, vel, h, ds, dtype=np.float32, mode="plane", pln_o=po, pln_d=pd)
-    assert np.array_equal(xt.cpu().numpy(), ref["xt"]) and np.array_equal(vt.cpu().numpy(), ref["vt"])
-    assert np.array_equal(fm.cpu().numpy().astype(bool), ref["failmask"])
+    for pair in (False, True):           # k_trace_flat<PAIR, 1>: plain grid and the pair copy of it
+        drrt_mod.options.pair_grid = pair
+        try:
+            xt, vt, fm = T.trace_pln(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), _t(po, gpu), _t(pd, gpu), h, ds)
+        finally:
+            drrt_mod.options.pair_grid = "auto"
+        assert np.array_equal(xt.cpu().numpy(), ref["xt"]) and np.array_equal(vt.cpu().numpy(), ref["vt"]), pair
+        assert np.array_equal(fm.cpu().numpy().astype(bool), ref["failmask"]), pair
     # targets beyond the far face (closest approach in free flight AFTER escape: exercises the
     # global-loop-count coupling, src/tracer.cpp:225-227), inside the volume, and behind the source
     for tgt in ([0.5, 1.3, 0.5], [0.5, 0.6, 0.5], [-0.4, 0.2, 0.5]):
@@ -672,14 +677,16 @@ def test_bricks_plane_second_pass_matches_default(gpu, oracle, drrt_mod):
     T = drrt_mod.TracerC()
     for sort in (False, True):
         drrt_mod.options.sort_rays = sort
-        for bricks in (False, True):
+        for bricks, pair in ((False, False), (True, False), (False, True)):
             drrt_mod.options.lds_bricks = bricks
+            drrt_mod.options.pair_grid = pair
             try:
                 xt, vt, fm = T.trace_pln(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), _t(po, gpu), _t(pd, gpu), h, ds)
             finally:
                 drrt_mod.options.lds_bricks = False
-            assert np.array_equal(xt.cpu().numpy(), ref["xt"]) and np.array_equal(vt.cpu().numpy(), ref["vt"]), (sort, bricks)
-            assert np.array_equal(fm.cpu().numpy().astype(bool), ref["failmask"]), (sort, bricks)
+                drrt_mod.options.pair_grid = "auto"
+            assert np.array_equal(xt.cpu().numpy(), ref["xt"]) and np.array_equal(vt.cpu().numpy(), ref["vt"]), (sort, bricks, pair)
+            assert np.array_equal(fm.cpu().numpy().astype(bool), ref["failmask"]), (sort, bricks, pair)
     drrt_mod.options.sort_rays = True
 
 
