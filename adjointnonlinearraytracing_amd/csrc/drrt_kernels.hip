@@ -1181,8 +1181,13 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
   }
 }
 
+#ifndef DRRT_ANCHOR_SHIFT
+#define DRRT_ANCHOR_SHIFT 0.35f   // how far the window is pushed towards the direction of travel when it is anchored (0.5 = all of it ahead);
+                                  // measured 256^3 / 1M rays, same box: 0.30 -> 4.85 ms, 0.35 -> 4.85, 0.40 -> 5.78 (trailing lanes miss), 0.45 -> 5.90
+#endif
 #ifndef DRRT_ADJ_WAVES
 #define DRRT_ADJ_WAVES 5     // 5 waves per SIMD: caps the kernel at 96 VGPRs (it sits right at that edge); LDS allows 5 blocks per CU too
+                             // (4 -> 4.89 ms, 5 -> 4.85, 6 -> 5.19 on the final kernel)
 #endif
 // PAIR: gather from the pair copy of the grid (two 16-byte loads per cell, see gather_rows).
 // DYN : windows with run-time dimensions, fitted to the wave's rays when the default kWin^3 window cannot hold them
@@ -1313,7 +1318,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
         {
           // default: a kWin^3 window around the median lane's cell, shifted towards the direction of travel
           if constexpr (DYN) { if (W.dx != kWinX || W.dy != kWinY || W.dz != kWinZ) win_set_dims(W, kWinX, kWinY, kWinZ); }
-          const float fx = 0.5f - 0.35f * (dx_ * inv_dm), fy = 0.5f - 0.35f * (dy_ * inv_dm), fz = 0.5f - 0.35f * (dz_ * inv_dm);
+          const float fx = 0.5f - DRRT_ANCHOR_SHIFT * (dx_ * inv_dm), fy = 0.5f - DRRT_ANCHOR_SHIFT * (dy_ * inv_dm), fz = 0.5f - DRRT_ANCHOR_SHIFT * (dz_ * inv_dm);
           int ox = rx - (int)(fx * (float)(kWinX - 2));
           int oy = ry - (int)(fy * (float)(kWinY - 2));
           int oz = rz - (int)(fz * (float)(kWinZ - 2));
