@@ -51,6 +51,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference/core")
+sys.dont_write_bytecode = True      # the reference tree is read-only for us: importing from it must not drop .pyc files there
 
 import cable as ref_cable      # noqa: E402
 import grid as ref_grid        # noqa: E402
