@@ -562,6 +562,42 @@ __global__ void __launch_bounds__(kBlock) k_target_a(TargetArgs a) {
   block_stats(a.stats, steps, failed);
 }
 
+// trace_target phase A on the flat march (see k_trace_flat): the same loop with the closest-approach record of
+// target_ray_a kept in registers (:216-227 -- updated on EVERY iteration, also the one that ends the march).
+template <bool PAIR>
+__global__ void __launch_bounds__(kBlock) k_target_a_flat(TargetArgs a) {
+  const Vol& V = a.vol;
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const TapRows R = tap_rows<PAIR>(V);
+  unsigned steps = 0, failed = 0;
+  size_t i;
+  if (ray_index(a.perm, t, a.n, i)) {
+    const Ray3 p = ld3(a.pos, i), u = ld3(a.vel, i), tg = ld3(a.target, i);
+    FlatRay r;
+    const FlatPlane P{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    flat_begin<PAIR>(V, R, r, p, u);
+    float bx = p.x, by = p.y, bz = p.z, bvx = u.x, bvy = u.y, bvz = u.z;          // :56-57
+    float best;
+    { const float ex = p.x - tg.x, ey = p.y - tg.y, ez = p.z - tg.z; best = dot3(ex, ey, ez, ex, ey, ez); }   // :200
+    for (int it = 0; it < a.max_steps; ++it) {
+      if (flat_advance<PAIR, 0>(V, P, a.ds, it, r)) gather_rows<PAIR>(R, r.off, r.q0, r.q1);
+      const float ex = r.x - tg.x, ey = r.y - tg.y, ez = r.z - tg.z;
+      const float cur = dot3(ex, ey, ez, ex, ey, ez);
+      if (cur < best) { bx = r.x; by = r.y; bz = r.z; bvx = r.vx; bvy = r.vy; bvz = r.vz; best = cur; }
+      if (!r.live) break;
+    }
+    const bool esc = !r.live;
+    steps = esc ? r.steps : (a.max_steps > 0 ? (unsigned)a.max_steps : 0u);
+    failed = esc ? 0u : 1u;
+    st3(a.xt, i, bx, by, bz); st3(a.vt, i, bvx, bvy, bvz); a.dist2[i] = best;
+    float* w = a.state;
+    w[0 * a.n + i] = r.x; w[1 * a.n + i] = r.y; w[2 * a.n + i] = r.z;
+    w[3 * a.n + i] = r.vx; w[4 * a.n + i] = r.vy; w[5 * a.n + i] = r.vz;
+    w[6 * a.n + i] = __uint_as_float(steps);
+  }
+  block_stats(a.stats, steps, failed);
+}
+
 __global__ void __launch_bounds__(kBlock) k_target_b(TargetArgs a) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.n) return;
@@ -2029,7 +2065,10 @@ extern "C" int drrt_trace_target_f32(const float* rif, long long nvox, const int
   if (rc) return rc;
   a.pos = pos; a.vel = vel; a.target = target; a.xt = xt; a.vt = vt; a.dist2 = dist2;
   a.stats = stats; a.n = n; a.ds = ds; a.max_steps = steps_fwd(h, res, ds);
-  hipLaunchKernelGGL(k_target_a, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+  rc = maybe_pair(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc;     // lies behind [state | sort buffers]
+  if (flags & DRRT_FLAG_LEGACY_FORWARD) hipLaunchKernelGGL(k_target_a, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+  else if (a.vol.pair != nullptr)       hipLaunchKernelGGL(k_target_a_flat<true>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
+  else                                  hipLaunchKernelGGL(k_target_a_flat<false>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
   LAUNCH_CHECK("k_target_a");
   hipLaunchKernelGGL(k_target_b, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
   LAUNCH_CHECK("k_target_b");

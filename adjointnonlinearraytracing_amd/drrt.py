@@ -360,7 +360,7 @@ class TracerC:
             xt, vt = torch.empty_like(pos_), torch.empty_like(vel_)
             d2 = torch.empty(n, dtype=torch.float32, device=dev)
             fl = _flags()
-            ws, st = _workspace(n, fl, dev), _new_stats(dev)
+            (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev), _new_stats(dev)
             _lib.check(_lib.load().drrt_trace_target_f32(
                 _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), _p(tg),
                 float(h), float(ds), _p(xt), _p(vt), _p(d2), _p(st), _p(ws), ws.numel(), fl,

@@ -84,7 +84,7 @@ extern "C" {
                                              loop without software pipelining (sample, bookkeeping, then step) */
 #define DRRT_FLAG_Q16_POS_ONLY 0x200000u  /* drrt_trace_q16io / drrt_backtrace_q16io: only the POSITION arrays are q16 codes;
                                              directions and adjoint seeds are fp32 arrays (18 B per exit ray instead of 12) */
-#define DRRT_FLAG_LEGACY_FORWARD 0x100000u /* trace, trace_pln (A-B measurement; bit-identical results): k_trace<MODE> instead of k_trace_flat */
+#define DRRT_FLAG_LEGACY_FORWARD 0x100000u /* trace, trace_pln, trace_target (A-B measurement; bit-identical results): k_trace<MODE> / k_target_a instead of the flat kernels */
 #define DRRT_FLAG_STATIC_WINDOW 0x400000u  /* backtrace (A-B measurement; same results up to fp32 summation order): always the
                                              kernel with compile-time 9^3 gradient windows, no per-call bundle classification */
 #define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace, backtrace_sdf (A-B measurement; same results up to fp32 summation order): the round-1

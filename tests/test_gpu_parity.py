@@ -277,13 +277,18 @@ def test_trace_plane_and_target(gpu, oracle, drrt_mod):
     # global-loop-count coupling, src/tracer.cpp:225-227), inside the volume, and behind the source
     for tgt in ([0.5, 1.3, 0.5], [0.5, 0.6, 0.5], [-0.4, 0.2, 0.5]):
         tg = np.tile(np.array([tgt], np.float32) * span, (len(pos), 1))
-        xt2, vt2, d2 = T.trace_target(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), _t(tg, gpu), h, ds)
-        st = drrt_mod.read_stats()
         with oracle.arith("factored"):
             ref2 = oracle.trace_target(rif, rif.shape, pos, vel, tg, h, ds, dtype=np.float32)
-        assert st["iters"] == ref2["iters"]
-        assert np.array_equal(xt2.cpu().numpy(), ref2["xt"]) and np.array_equal(vt2.cpu().numpy(), ref2["vt"])
-        assert np.array_equal(d2.cpu().numpy(), ref2["dist2"])
+        for pair in (False, True):       # k_target_a_flat<PAIR>
+            drrt_mod.options.pair_grid = pair
+            try:
+                xt2, vt2, d2 = T.trace_target(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), _t(tg, gpu), h, ds)
+            finally:
+                drrt_mod.options.pair_grid = "auto"
+            st = drrt_mod.read_stats()
+            assert st["iters"] == ref2["iters"], pair
+            assert np.array_equal(xt2.cpu().numpy(), ref2["xt"]) and np.array_equal(vt2.cpu().numpy(), ref2["vt"]), pair
+            assert np.array_equal(d2.cpu().numpy(), ref2["dist2"]), pair
     ref64 = oracle.trace_target(rif, rif.shape, pos, vel, tg, h, ds, dtype=np.float64)
     assert np.mean(np.abs(d2.cpu().numpy() - ref64["dist2"]) <= 1e-5) >= 0.99
 
