@@ -75,6 +75,12 @@ SIGNATURES = {
     "drrt_sensor_far_splat_bwd_f32": (_i, [_sz, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "drrt_sensor_tex_get_f32": (_i, [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp]),
     "drrt_sensor_tex_get_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "drrt_sensor_splat_dframe_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _i, _f, _vp, _u, _vp]),
+    "drrt_sensor_splat_dframe_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "drrt_sensor_far_splat_dframe_f32": (_i, [_sz, _vp, _vp, _f, _vp, _i, _f, _vp, _u, _vp]),
+    "drrt_sensor_far_splat_dframe_bwd_f32": (_i, [_sz, _vp, _vp, _f, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "drrt_sensor_tex_get_dframe_f32": (_i, [_sz, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp]),
+    "drrt_sensor_tex_get_dframe_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "drrt_rays_to_plane_f32": (_i, [_sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "drrt_rays_to_plane_bwd_f32": (_i, [_sz, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "drrt_upres_volume_f32": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -28,6 +28,8 @@ struct SensorArgs {
   const float* x; const float* v; const float* e;   // e nullable -> e_scalar
   float e_scalar;
   float p[3], n[3], t1[3], t2[3];
+  const float* frame_dev;      // nullable: 12 device floats (p, n, t1, t2) read by the kernel INSTEAD of the four above --
+                               // the *_dframe entries: a caller whose plane lives on the device needs no host copy / sync
   int res; float span, inv_hs, half_span;
   int far;                     // 1: generate_inf_sensor (coordinates from the direction only; span = 2*ang_cut);
                                // 2: get_sdf_vals_far (coordinates from the UN-normalised direction, sensor.py:134)
@@ -38,6 +40,13 @@ struct SensorArgs {
   float* grad_x; float* grad_v;
   size_t n_rays;
 };
+
+__device__ __forceinline__ void sensor_frame(SensorArgs& a) {       // wave-uniform scalar loads
+  if (a.frame_dev != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a.p[k] = a.frame_dev[k]; a.n[k] = a.frame_dev[3 + k]; a.t1[k] = a.frame_dev[6 + k]; a.t2[k] = a.frame_dev[9 + k]; }
+  }
+}
 
 struct SensorRay {
   float den, t, F, u[2];
@@ -88,6 +97,7 @@ constexpr int kTile = 48;                       // tile edge in pixels (48*48 do
 constexpr int kVoteCell = 32, kVote = 40;       // anchor vote: 40x40 coarse cells of 32 pixels (images up to 1277^2; larger ones clamp)
 
 __global__ void __launch_bounds__(256) k_sensor_splat(SensorArgs a) {
+  sensor_frame(a);
   __shared__ double s_tile[kTile * kTile];
   __shared__ unsigned s_vote[kVote * kVote];
   __shared__ int s_min[2];
@@ -168,6 +178,7 @@ __global__ void __launch_bounds__(256) k_sensor_splat(SensorArgs a) {
 }
 
 __global__ void __launch_bounds__(256) k_sensor_splat_bwd(SensorArgs a) {
+  sensor_frame(a);
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_rays) return;
   float x[3], v[3];
@@ -257,6 +268,7 @@ __device__ __forceinline__ TexTaps tex_taps(const SensorArgs& a, const SensorRay
 }
 
 __global__ void __launch_bounds__(256) k_sensor_tex_get(SensorArgs a) {
+  sensor_frame(a);
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_rays) return;
   float x[3], v[3];
@@ -267,6 +279,7 @@ __global__ void __launch_bounds__(256) k_sensor_tex_get(SensorArgs a) {
 }
 
 __global__ void __launch_bounds__(256) k_sensor_tex_get_bwd(SensorArgs a) {
+  sensor_frame(a);
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_rays) return;
   float x[3], v[3];
@@ -293,9 +306,12 @@ __global__ void __launch_bounds__(256) k_sensor_tex_get_bwd(SensorArgs a) {
 
 int sensor_fail(int code, const char* msg);   // drrt_kernels.hip
 
+static const float kZero3[3] = {0.f, 0.f, 0.f};
+
 static int fill_args(SensorArgs& a, size_t n, const float* x, const float* v, const float* e, float e_scalar,
                      const float p[3], const float nrm[3], const float t1[3], const float t2[3], int res, float span) {
   if (!x || !v || !p || !nrm || !t1 || !t2) return sensor_fail(DRRT_ERR_ARG, "null pointer");
+  a.frame_dev = nullptr;
   if (res < 1 || res > 32768 || !(span > 0.f)) return sensor_fail(DRRT_ERR_ARG, "bad sensor resolution / span");
   a.x = x; a.v = v; a.e = e; a.e_scalar = e_scalar; a.n_rays = n;
   for (int k = 0; k < 3; ++k) { a.p[k] = p[k]; a.n[k] = nrm[k]; a.t1[k] = t1[k]; a.t2[k] = t2[k]; }
@@ -308,12 +324,12 @@ static int fill_args(SensorArgs& a, size_t n, const float* x, const float* v, co
 
 using namespace drrt;
 
-extern "C" int drrt_sensor_splat_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
-                                     const float plane_p[3], const float plane_n[3], const float t1[3],
-                                     const float t2[3], int res, float span, float* image, unsigned flags,
-                                     void* stream) {
+static int splat_fwd(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                     const float plane_p[3], const float plane_n[3], const float t1[3], const float t2[3],
+                     const float* frame_dev, int res, float span, float* image, unsigned flags, void* stream) {
   SensorArgs a{};
   int rc = fill_args(a, n, x, v, e, e_scalar, plane_p, plane_n, t1, t2, res, span); if (rc) return rc;
+  a.frame_dev = frame_dev;
   if (!image) return sensor_fail(DRRT_ERR_ARG, "null image pointer");
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & DRRT_FLAG_NO_ZERO)) {
@@ -323,6 +339,34 @@ extern "C" int drrt_sensor_splat_f32(size_t n, const float* x, const float* v, c
   if (n == 0) return DRRT_OK;
   a.image = image;
   hipLaunchKernelGGL(k_sensor_splat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  hipError_t le = hipGetLastError();
+  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+
+extern "C" int drrt_sensor_splat_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                                     const float plane_p[3], const float plane_n[3], const float t1[3],
+                                     const float t2[3], int res, float span, float* image, unsigned flags,
+                                     void* stream) {
+  return splat_fwd(n, x, v, e, e_scalar, plane_p, plane_n, t1, t2, nullptr, res, span, image, flags, stream);
+}
+extern "C" int drrt_sensor_splat_dframe_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                                            const float* frame12, int res, float span, float* image, unsigned flags,
+                                            void* stream) {
+  if (!frame12) return sensor_fail(DRRT_ERR_ARG, "null frame pointer");
+  return splat_fwd(n, x, v, e, e_scalar, kZero3, kZero3, kZero3, kZero3, frame12, res, span, image, flags, stream);
+}
+
+static int splat_bwd(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                     const float plane_p[3], const float plane_n[3], const float t1[3], const float t2[3],
+                     const float* frame_dev, int res, float span, const float* grad_image, float* grad_x, float* grad_v,
+                     void* stream) {
+  SensorArgs a{};
+  int rc = fill_args(a, n, x, v, e, e_scalar, plane_p, plane_n, t1, t2, res, span); if (rc) return rc;
+  a.frame_dev = frame_dev;
+  if (!grad_image || !grad_x || !grad_v) return sensor_fail(DRRT_ERR_ARG, "null gradient pointer");
+  if (n == 0) return DRRT_OK;
+  a.grad_image = grad_image; a.grad_x = grad_x; a.grad_v = grad_v;
+  hipLaunchKernelGGL(k_sensor_splat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   hipError_t le = hipGetLastError();
   return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
 }
@@ -331,33 +375,32 @@ extern "C" int drrt_sensor_splat_bwd_f32(size_t n, const float* x, const float* 
                                          const float plane_p[3], const float plane_n[3], const float t1[3],
                                          const float t2[3], int res, float span, const float* grad_image,
                                          float* grad_x, float* grad_v, void* stream) {
-  SensorArgs a{};
-  int rc = fill_args(a, n, x, v, e, e_scalar, plane_p, plane_n, t1, t2, res, span); if (rc) return rc;
-  if (!grad_image || !grad_x || !grad_v) return sensor_fail(DRRT_ERR_ARG, "null gradient pointer");
-  if (n == 0) return DRRT_OK;
-  a.grad_image = grad_image; a.grad_x = grad_x; a.grad_v = grad_v;
-  hipLaunchKernelGGL(k_sensor_splat_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-  hipError_t le = hipGetLastError();
-  return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+  return splat_bwd(n, x, v, e, e_scalar, plane_p, plane_n, t1, t2, nullptr, res, span, grad_image, grad_x, grad_v, stream);
+}
+extern "C" int drrt_sensor_splat_dframe_bwd_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                                                const float* frame12, int res, float span, const float* grad_image,
+                                                float* grad_x, float* grad_v, void* stream) {
+  if (!frame12) return sensor_fail(DRRT_ERR_ARG, "null frame pointer");
+  return splat_bwd(n, x, v, e, e_scalar, kZero3, kZero3, kZero3, kZero3, frame12, res, span, grad_image, grad_x, grad_v, stream);
 }
 
 // ---- far-field sensor (core/sensor.py:31-53 generate_inf_sensor, called at core/image_opt.py:116) ----------------
 // Same splat kernels with SensorArgs::far set: `ang_cut` = sin(0.5 * deg2rad(angle_span)) is computed by the caller
 // (the reference evaluates it in the rays' dtype, sensor.py:38); the image spans [0, 2*ang_cut)^2.
 static int fill_far(SensorArgs& a, size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
-                    const float t2[3], int res, float ang_cut) {
+                    const float t2[3], const float* frame_dev, int res, float ang_cut) {
   const float zero[3] = {0.f, 0.f, 0.f};
   int rc = fill_args(a, n, v, v, e, e_scalar, zero, zero, t1, t2, res, 2.0f * ang_cut); if (rc) return rc;
+  a.frame_dev = frame_dev;              // (the far field reads t1, t2 only; p and n are not used)
   a.half_span = ang_cut; a.inv_hs = 1.0f / (2.0f * ang_cut / (float)res);   // Grid(zeros, 2*ang_cut/res), :44
   a.far = 1;
   return DRRT_OK;
 }
 
-extern "C" int drrt_sensor_far_splat_f32(size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
-                                         const float t2[3], int res, float ang_cut, float* image, unsigned flags,
-                                         void* stream) {
+static int far_fwd(size_t n, const float* v, const float* e, float e_scalar, const float t1[3], const float t2[3],
+                   const float* frame_dev, int res, float ang_cut, float* image, unsigned flags, void* stream) {
   SensorArgs a{};
-  int rc = fill_far(a, n, v, e, e_scalar, t1, t2, res, ang_cut); if (rc) return rc;
+  int rc = fill_far(a, n, v, e, e_scalar, t1, t2, frame_dev, res, ang_cut); if (rc) return rc;
   if (!image) return sensor_fail(DRRT_ERR_ARG, "null image pointer");
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & DRRT_FLAG_NO_ZERO)) {
@@ -371,11 +414,23 @@ extern "C" int drrt_sensor_far_splat_f32(size_t n, const float* v, const float* 
   return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
 }
 
-extern "C" int drrt_sensor_far_splat_bwd_f32(size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
-                                             const float t2[3], int res, float ang_cut, const float* grad_image,
-                                             float* grad_x, float* grad_v, void* stream) {
+extern "C" int drrt_sensor_far_splat_f32(size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
+                                         const float t2[3], int res, float ang_cut, float* image, unsigned flags,
+                                         void* stream) {
+  return far_fwd(n, v, e, e_scalar, t1, t2, nullptr, res, ang_cut, image, flags, stream);
+}
+extern "C" int drrt_sensor_far_splat_dframe_f32(size_t n, const float* v, const float* e, float e_scalar,
+                                                const float* frame12, int res, float ang_cut, float* image,
+                                                unsigned flags, void* stream) {
+  if (!frame12) return sensor_fail(DRRT_ERR_ARG, "null frame pointer");
+  return far_fwd(n, v, e, e_scalar, kZero3, kZero3, frame12, res, ang_cut, image, flags, stream);
+}
+
+static int far_bwd(size_t n, const float* v, const float* e, float e_scalar, const float t1[3], const float t2[3],
+                   const float* frame_dev, int res, float ang_cut, const float* grad_image, float* grad_x, float* grad_v,
+                   void* stream) {
   SensorArgs a{};
-  int rc = fill_far(a, n, v, e, e_scalar, t1, t2, res, ang_cut); if (rc) return rc;
+  int rc = fill_far(a, n, v, e, e_scalar, t1, t2, frame_dev, res, ang_cut); if (rc) return rc;
   if (!grad_image || !grad_x || !grad_v) return sensor_fail(DRRT_ERR_ARG, "null gradient pointer");
   if (n == 0) return DRRT_OK;
   a.grad_image = grad_image; a.grad_x = grad_x; a.grad_v = grad_v;
@@ -384,13 +439,27 @@ extern "C" int drrt_sensor_far_splat_bwd_f32(size_t n, const float* v, const flo
   return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
 }
 
+extern "C" int drrt_sensor_far_splat_bwd_f32(size_t n, const float* v, const float* e, float e_scalar, const float t1[3],
+                                             const float t2[3], int res, float ang_cut, const float* grad_image,
+                                             float* grad_x, float* grad_v, void* stream) {
+  return far_bwd(n, v, e, e_scalar, t1, t2, nullptr, res, ang_cut, grad_image, grad_x, grad_v, stream);
+}
+extern "C" int drrt_sensor_far_splat_dframe_bwd_f32(size_t n, const float* v, const float* e, float e_scalar,
+                                                    const float* frame12, int res, float ang_cut,
+                                                    const float* grad_image, float* grad_x, float* grad_v, void* stream) {
+  if (!frame12) return sensor_fail(DRRT_ERR_ARG, "null frame pointer");
+  return far_bwd(n, v, e, e_scalar, kZero3, kZero3, frame12, res, ang_cut, grad_image, grad_x, grad_v, stream);
+}
+
 // ---- texture lookups at the sensor (core/sensor.py:102-138), see k_sensor_tex_get ------------------------------------
 // mode 0: get_sdf_vals_near (rays -> plane -> sensor frame, cell size span / res);
 // mode 1: get_sdf_vals_far  (coordinates v . T + ang_cut from the direction as it is, cell size 2 ang_cut / res; pass
 //         span = 2 * ang_cut).
 static int fill_tex(SensorArgs& a, size_t n, const float* x, const float* v, const float p[3], const float nrm[3],
-                    const float t1[3], const float t2[3], int res, float span, int mode, const float* tex) {
+                    const float t1[3], const float t2[3], const float* frame_dev, int res, float span, int mode,
+                    const float* tex) {
   int rc = fill_args(a, n, x, v, nullptr, 1.f, p, nrm, t1, t2, res, span); if (rc) return rc;
+  a.frame_dev = frame_dev;
   if (!tex) return sensor_fail(DRRT_ERR_ARG, "null texture pointer");
   if (mode != 0 && mode != 1) return sensor_fail(DRRT_ERR_ARG, "mode must be 0 (near) or 1 (far)");
   a.far = mode == 1 ? 2 : 0;
@@ -398,11 +467,11 @@ static int fill_tex(SensorArgs& a, size_t n, const float* x, const float* v, con
   return DRRT_OK;
 }
 
-extern "C" int drrt_sensor_tex_get_f32(size_t n, const float* x, const float* v, const float plane_p[3],
-                                       const float plane_n[3], const float t1[3], const float t2[3], const float* tex,
-                                       int res, float span, int mode, float* f_out, void* stream) {
+static int tex_fwd(size_t n, const float* x, const float* v, const float plane_p[3], const float plane_n[3],
+                   const float t1[3], const float t2[3], const float* frame_dev, const float* tex, int res, float span,
+                   int mode, float* f_out, void* stream) {
   SensorArgs a{};
-  int rc = fill_tex(a, n, x, v, plane_p, plane_n, t1, t2, res, span, mode, tex); if (rc) return rc;
+  int rc = fill_tex(a, n, x, v, plane_p, plane_n, t1, t2, frame_dev, res, span, mode, tex); if (rc) return rc;
   if (n == 0) return DRRT_OK;
   if (!f_out) return sensor_fail(DRRT_ERR_ARG, "null output pointer");
   a.f_out = f_out;
@@ -411,18 +480,41 @@ extern "C" int drrt_sensor_tex_get_f32(size_t n, const float* x, const float* v,
   return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
 }
 
-extern "C" int drrt_sensor_tex_get_bwd_f32(size_t n, const float* x, const float* v, const float plane_p[3],
-                                           const float plane_n[3], const float t1[3], const float t2[3],
-                                           const float* tex, int res, float span, int mode, const float* grad_f,
-                                           float* grad_x, float* grad_v, void* stream) {
+extern "C" int drrt_sensor_tex_get_f32(size_t n, const float* x, const float* v, const float plane_p[3],
+                                       const float plane_n[3], const float t1[3], const float t2[3], const float* tex,
+                                       int res, float span, int mode, float* f_out, void* stream) {
+  return tex_fwd(n, x, v, plane_p, plane_n, t1, t2, nullptr, tex, res, span, mode, f_out, stream);
+}
+extern "C" int drrt_sensor_tex_get_dframe_f32(size_t n, const float* x, const float* v, const float* frame12,
+                                              const float* tex, int res, float span, int mode, float* f_out, void* stream) {
+  if (!frame12) return sensor_fail(DRRT_ERR_ARG, "null frame pointer");
+  return tex_fwd(n, x, v, kZero3, kZero3, kZero3, kZero3, frame12, tex, res, span, mode, f_out, stream);
+}
+
+static int tex_bwd(size_t n, const float* x, const float* v, const float plane_p[3], const float plane_n[3],
+                   const float t1[3], const float t2[3], const float* frame_dev, const float* tex, int res, float span,
+                   int mode, const float* grad_f, float* grad_x, float* grad_v, void* stream) {
   SensorArgs a{};
-  int rc = fill_tex(a, n, x, v, plane_p, plane_n, t1, t2, res, span, mode, tex); if (rc) return rc;
+  int rc = fill_tex(a, n, x, v, plane_p, plane_n, t1, t2, frame_dev, res, span, mode, tex); if (rc) return rc;
   if (n == 0) return DRRT_OK;
   if (!grad_f || !grad_x || !grad_v) return sensor_fail(DRRT_ERR_ARG, "null gradient pointer");
   a.grad_f = grad_f; a.grad_x = grad_x; a.grad_v = grad_v;
   hipLaunchKernelGGL(k_sensor_tex_get_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   hipError_t le = hipGetLastError();
   return le == hipSuccess ? DRRT_OK : sensor_fail(DRRT_ERR_HIP, hipGetErrorString(le));
+}
+
+extern "C" int drrt_sensor_tex_get_bwd_f32(size_t n, const float* x, const float* v, const float plane_p[3],
+                                           const float plane_n[3], const float t1[3], const float t2[3],
+                                           const float* tex, int res, float span, int mode, const float* grad_f,
+                                           float* grad_x, float* grad_v, void* stream) {
+  return tex_bwd(n, x, v, plane_p, plane_n, t1, t2, nullptr, tex, res, span, mode, grad_f, grad_x, grad_v, stream);
+}
+extern "C" int drrt_sensor_tex_get_dframe_bwd_f32(size_t n, const float* x, const float* v, const float* frame12,
+                                                  const float* tex, int res, float span, int mode, const float* grad_f,
+                                                  float* grad_x, float* grad_v, void* stream) {
+  if (!frame12) return sensor_fail(DRRT_ERR_ARG, "null frame pointer");
+  return tex_bwd(n, x, v, kZero3, kZero3, kZero3, kZero3, frame12, tex, res, span, mode, grad_f, grad_x, grad_v, stream);
 }
 
 // =============================================================================================

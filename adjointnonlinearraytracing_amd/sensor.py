@@ -92,6 +92,25 @@ def _vec3(t: torch.Tensor):
     return (C.c_float * 3)(*v)
 
 
+def _frame(dev, p, n, t1, t2):
+    """The sensor frame of a call -> (frame12, host): when every given vector is a tensor on `dev` (the reference keeps
+    its planes there, core/image_opt.py:88-119) they are packed into ONE 12-float device tensor (p, n, t1, t2; zeros for
+    p / n of the far field) for the *_dframe entries -- no copy back to the host, hence no device sync per call;
+    otherwise host float[3] arrays for the plain entries."""
+    given = [t for t in (p, n, t1, t2) if t is not None]
+    if all(isinstance(t, torch.Tensor) and t.is_cuda and t.device == dev for t in given):
+        zero = None
+        parts = []
+        for t in (p, n, t1, t2):
+            if t is None:
+                zero = torch.zeros(3, dtype=torch.float32, device=dev) if zero is None else zero
+                parts.append(zero)
+            else:
+                parts.append(t.detach().reshape(-1)[:3].to(torch.float32))
+        return torch.cat(parts).contiguous(), None
+    return None, tuple(_vec3(t) for t in given)
+
+
 class _SensorSplat(torch.autograd.Function):
 
     @staticmethod
@@ -111,26 +130,30 @@ class _SensorSplat(torch.autograd.Function):
             else:
                 e_, e_s = None, float(e)
             img = torch.empty(int(res), int(res), dtype=torch.float32, device=dev)
-            frame = (_vec3(p), _vec3(n), _vec3(t1), _vec3(t2))
-            _lib.check(_lib.load().drrt_sensor_splat_f32(
-                nr, C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()),
-                C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s, *frame, int(res), float(span),
-                C.c_void_p(img.data_ptr()), 0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        ctx.saved = (x_, v_, e_, e_s, frame, int(res), float(span))
+            fdev, frame = _frame(dev, p, n, t1, t2)
+            head = (nr, C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()), C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s)
+            tail = (int(res), float(span), C.c_void_p(img.data_ptr()), 0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if fdev is not None:
+                _lib.check(_lib.load().drrt_sensor_splat_dframe_f32(*head, C.c_void_p(fdev.data_ptr()), *tail))
+            else:
+                _lib.check(_lib.load().drrt_sensor_splat_f32(*head, *frame, *tail))
+        ctx.saved = (x_, v_, e_, e_s, fdev, frame, int(res), float(span))
         return img
 
     @staticmethod
     def backward(ctx, grad_img):
-        x_, v_, e_, e_s, frame, res, span = ctx.saved
+        x_, v_, e_, e_s, fdev, frame, res, span = ctx.saved
         dev = x_.device
         with torch.cuda.device(dev):
             g = grad_img.detach().to(torch.float32).contiguous()
             gx, gv = torch.empty_like(x_), torch.empty_like(v_)
-            _lib.check(_lib.load().drrt_sensor_splat_bwd_f32(
-                x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()),
-                C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s, *frame, res, span,
-                C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()), C.c_void_p(gv.data_ptr()),
-                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            head = (x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()), C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s)
+            tail = (res, span, C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()), C.c_void_p(gv.data_ptr()),
+                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if fdev is not None:
+                _lib.check(_lib.load().drrt_sensor_splat_dframe_bwd_f32(*head, C.c_void_p(fdev.data_ptr()), *tail))
+            else:
+                _lib.check(_lib.load().drrt_sensor_splat_bwd_f32(*head, *frame, *tail))
         return gx, gv, None, None, None, None, None, None, None
 
 
@@ -162,25 +185,30 @@ class _FarSensorSplat(torch.autograd.Function):
             else:
                 e_, e_s = None, float(e)
             img = torch.empty(int(res), int(res), dtype=torch.float32, device=dev)
-            frame = (_vec3(t1), _vec3(t2))
-            _lib.check(_lib.load().drrt_sensor_far_splat_f32(
-                nr, C.c_void_p(v_.data_ptr()), C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s, *frame,
-                int(res), float(ang_cut), C.c_void_p(img.data_ptr()), 0,
-                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        ctx.saved = (v_, e_, e_s, frame, int(res), float(ang_cut))
+            fdev, frame = _frame(dev, None, None, t1, t2)
+            head = (nr, C.c_void_p(v_.data_ptr()), C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s)
+            tail = (int(res), float(ang_cut), C.c_void_p(img.data_ptr()), 0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if fdev is not None:
+                _lib.check(_lib.load().drrt_sensor_far_splat_dframe_f32(*head, C.c_void_p(fdev.data_ptr()), *tail))
+            else:
+                _lib.check(_lib.load().drrt_sensor_far_splat_f32(*head, *frame, *tail))
+        ctx.saved = (v_, e_, e_s, fdev, frame, int(res), float(ang_cut))
         return img
 
     @staticmethod
     def backward(ctx, grad_img):
-        v_, e_, e_s, frame, res, ang_cut = ctx.saved
+        v_, e_, e_s, fdev, frame, res, ang_cut = ctx.saved
         dev = v_.device
         with torch.cuda.device(dev):
             g = grad_img.detach().to(torch.float32).contiguous()
             gx, gv = torch.empty_like(v_), torch.empty_like(v_)
-            _lib.check(_lib.load().drrt_sensor_far_splat_bwd_f32(
-                v_.shape[0], C.c_void_p(v_.data_ptr()), C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s, *frame,
-                res, ang_cut, C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()), C.c_void_p(gv.data_ptr()),
-                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            head = (v_.shape[0], C.c_void_p(v_.data_ptr()), C.c_void_p(0 if e_ is None else e_.data_ptr()), e_s)
+            tail = (res, ang_cut, C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()), C.c_void_p(gv.data_ptr()),
+                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if fdev is not None:
+                _lib.check(_lib.load().drrt_sensor_far_splat_dframe_bwd_f32(*head, C.c_void_p(fdev.data_ptr()), *tail))
+            else:
+                _lib.check(_lib.load().drrt_sensor_far_splat_bwd_f32(*head, *frame, *tail))
         return gv, None, None, None, None, None
 
 
@@ -208,26 +236,32 @@ class _TexGet(torch.autograd.Function):
             tex_ = tex.detach().to(device=dev, dtype=torch.float32).contiguous()
             if tex_.dim() != 2 or tex_.shape[0] != tex_.shape[1]:
                 raise RuntimeError("the texture must be square (the reference clips both axes with res[0])")
-            frame = (_vec3(p), _vec3(n), _vec3(t1), _vec3(t2))
+            fdev, frame = _frame(dev, p, n, t1, t2)
             f = torch.empty(x_.shape[0], dtype=torch.float32, device=dev)
-            _lib.check(_lib.load().drrt_sensor_tex_get_f32(
-                x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()), *frame, C.c_void_p(tex_.data_ptr()),
-                int(tex_.shape[0]), float(span), int(mode), C.c_void_p(f.data_ptr()),
-                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        ctx.saved = (x_, v_, tex_, frame, float(span), int(mode))
+            head = (x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()))
+            tail = (C.c_void_p(tex_.data_ptr()), int(tex_.shape[0]), float(span), int(mode), C.c_void_p(f.data_ptr()),
+                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if fdev is not None:
+                _lib.check(_lib.load().drrt_sensor_tex_get_dframe_f32(*head, C.c_void_p(fdev.data_ptr()), *tail))
+            else:
+                _lib.check(_lib.load().drrt_sensor_tex_get_f32(*head, *frame, *tail))
+        ctx.saved = (x_, v_, tex_, fdev, frame, float(span), int(mode))
         return f
 
     @staticmethod
     def backward(ctx, grad_f):
-        x_, v_, tex_, frame, span, mode = ctx.saved
+        x_, v_, tex_, fdev, frame, span, mode = ctx.saved
         dev = x_.device
         with torch.cuda.device(dev):
             g = grad_f.detach().to(torch.float32).contiguous()
             gx, gv = torch.empty_like(x_), torch.empty_like(v_)
-            _lib.check(_lib.load().drrt_sensor_tex_get_bwd_f32(
-                x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()), *frame, C.c_void_p(tex_.data_ptr()),
-                int(tex_.shape[0]), span, mode, C.c_void_p(g.data_ptr()), C.c_void_p(gx.data_ptr()),
-                C.c_void_p(gv.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            head = (x_.shape[0], C.c_void_p(x_.data_ptr()), C.c_void_p(v_.data_ptr()))
+            tail = (C.c_void_p(tex_.data_ptr()), int(tex_.shape[0]), span, mode, C.c_void_p(g.data_ptr()),
+                    C.c_void_p(gx.data_ptr()), C.c_void_p(gv.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if fdev is not None:
+                _lib.check(_lib.load().drrt_sensor_tex_get_dframe_bwd_f32(*head, C.c_void_p(fdev.data_ptr()), *tail))
+            else:
+                _lib.check(_lib.load().drrt_sensor_tex_get_bwd_f32(*head, *frame, *tail))
         return gx, gv, None, None, None, None, None, None, None
 
 

@@ -317,6 +317,26 @@ DRRT_API int drrt_sensor_tex_get_bwd_f32(size_t n, const float* x, const float* 
                                 const float plane_n[3], const float t1[3], const float t2[3], const float* tex, int res,
                                 float span, int mode, const float* grad_f, float* grad_x, float* grad_v, void* stream);
 
+/* The same six sensor operators with the sensor frame in DEVICE memory: frame12 = 12 fp32 values (plane_p, plane_n, t1, t2;
+ * the far-field entries read t1, t2 only).  The reference keeps its planes as torch tensors on the device (core/image_opt.py
+ * :88-119 slices them from the ray generator's output), so a caller of the host-pointer entries above has to copy them back
+ * first -- a device synchronisation per call.  These entries need none; results are identical.                            */
+DRRT_API int drrt_sensor_splat_dframe_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                                 const float* frame12, int res, float span, float* image, unsigned flags, void* stream);
+DRRT_API int drrt_sensor_splat_dframe_bwd_f32(size_t n, const float* x, const float* v, const float* e, float e_scalar,
+                                     const float* frame12, int res, float span, const float* grad_image, float* grad_x,
+                                     float* grad_v, void* stream);
+DRRT_API int drrt_sensor_far_splat_dframe_f32(size_t n, const float* v, const float* e, float e_scalar, const float* frame12,
+                                     int res, float ang_cut, float* image, unsigned flags, void* stream);
+DRRT_API int drrt_sensor_far_splat_dframe_bwd_f32(size_t n, const float* v, const float* e, float e_scalar,
+                                         const float* frame12, int res, float ang_cut, const float* grad_image,
+                                         float* grad_x, float* grad_v, void* stream);
+DRRT_API int drrt_sensor_tex_get_dframe_f32(size_t n, const float* x, const float* v, const float* frame12, const float* tex,
+                                   int res, float span, int mode, float* f_out, void* stream);
+DRRT_API int drrt_sensor_tex_get_dframe_bwd_f32(size_t n, const float* x, const float* v, const float* frame12,
+                                       const float* tex, int res, float span, int mode, const float* grad_f,
+                                       float* grad_x, float* grad_v, void* stream);
+
 /* core/sensor.py:195-202 trace_rays_to_plane, the statement right after the march in every experiment: x_out = x + t v with
  * t = n.(p - x) / n.v (v passes through unchanged), and its analytic backward w.r.t. the rays (grad_x, grad_v receive the
  * part of the gradient that flows through x_out).  plane_stride 3 = one (p, n) per ray, 0 = one plane for all rays.
