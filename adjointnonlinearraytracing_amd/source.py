@@ -101,7 +101,12 @@ def _generate(view_mats, pixels, spp, width, circle, sensor_dist, independent, o
             _lib.check(lib.drrt_gen_rays_f32(
                 int(kind), C.c_void_p(u.data_ptr()), C.c_void_p(rots.data_ptr()), nv, spp, p0, p1, float(width),
                 float(sensor_dist), int(bool(circle)), int(bool(independent)), *tail))
-        pre = counts.cpu().tolist()               # the one host sync (the reference syncs on its boolean mask too)
+        if kind == 2 or not circle:
+            # no rejection (only the disc mask drops samples, csrc/drrt_source.hip): the counts are known on the host,
+            # so the call returns without waiting for the device
+            per = spp * p0 * p1
+            return (x, v, planes), [per] * nv
+        pre = counts.cpu().tolist()               # disc mask: the one host sync (the reference syncs on its boolean mask too)
     total = pre[-1]
     nrays = [pre[i + 1] - pre[i] for i in range(nv)]
     return (x[:total], v[:total], planes[:total]), nrays
