@@ -2,6 +2,8 @@
 cases (bench.py measures only the metric workload).  Oracle comparisons use the full ray set where
 the CPU oracle finishes in seconds and a strided sub-sample otherwise; the rest is covered by
 size-independent properties (shard-sum, linearity, energy conservation)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -432,3 +434,40 @@ def test_config1_adjoint_vs_fp64_on_tie_free_rays(gpu, oracle, D):
     assert b["hip_all_vs_f64"] <= 5e-2
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(report, open(os.path.join("gpurun_out", "tie_report.json"), "w"), indent=1)
+
+
+def test_metric_workload_runs_on_the_fast_kernels(gpu, D):
+    """Guard, not a benchmark: the metric's workload (256^3 Luneburg ball, 1M plane-source rays, ds = h/2) through the
+    drop-in API must run on the windowed / flat kernels -- the one-atomic-per-tap adjoint takes ~240 ms, an unsorted
+    ray set ~25 ms, the product 1.1 + 4.9 ms on an MI355X.  Limits are 3x the measured times so that box-to-box variation
+    cannot trip them, while a silent fallback to a slow path does."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from adjointnonlinearraytracing_amd import _lib
+    R, n = 256, 1 << 20
+    rif, pos, vel, h, ds = bench.make_workload(R, n, gpu, seed=0)
+    T = D.TracerC()
+    res = (R, R, R)
+    lib = _lib.load()
+    for _ in range(2):                                   # warm-up (workspace allocation, first-launch costs)
+        xt, vt = T.trace(rif.reshape(-1), res, pos, vel, h, ds)
+        order = D.last_order
+        ones = torch.ones_like(xt)
+        g = T.backtrace(rif.reshape(-1), res, xt, vt, ones, ones, h, ds, order=order)
+    torch.cuda.synchronize(gpu)
+    _lib.check(lib.drrt_profile_begin(64))
+    try:
+        xt, vt = T.trace(rif.reshape(-1), res, pos, vel, h, ds)
+        order = D.last_order
+        g = T.backtrace(rif.reshape(-1), res, xt, vt, ones, ones, h, ds, order=order)
+        prof = dict()
+        for name, ms in _lib.profile_collect():
+            prof[name] = prof.get(name, 0.0) + ms
+    finally:
+        lib.drrt_profile_end()
+    st = D.read_stats()
+    assert st["n_failed"] == 0 and 4.5e8 < st["ray_steps"] < 5.5e8
+    assert float(g.abs().sum()) > 0.0
+    assert prof.get("trace", 1e9) < 3.3, prof            # measured 1.07 ms
+    assert prof.get("backtrace", 1e9) < 15.0, prof       # measured 4.85 ms
