@@ -1771,7 +1771,11 @@ extern "C" int drrt_profile_collect(int* ids, float* ms, int max_out) {
   g_prof_n = 0;
   return n;
 }
-extern "C" const char* drrt_version(void) { return "drrt_hip 0.1 gfx950"; }
+#ifndef DRRT_SRC_ID
+#define DRRT_SRC_ID "unknown"
+#endif
+// "drrt_hip <abi> gfx950 src:<digest of the sources, csrc/Makefile>"
+extern "C" const char* drrt_version(void) { return "drrt_hip 0.3 gfx950 src:" DRRT_SRC_ID; }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

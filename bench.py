@@ -48,8 +48,8 @@ B_ADJ = 64.0                   # adjoint: 8 taps read + 8 fp32 atomic adds
 # Committed rocprofv3 PMC summary (tools/profile_bench.sh + tools/condense_profile.py on THIS command) that
 # `roofline.traffic` and the physical-bound figures are read from.  It is NOT measured in the run: the
 # bench line says so in `traffic_source` / `pmc_source`.
-PMC_PROFILE = os.path.join("profiles", "r2_pmc.json")
-PMC_FALLBACK = os.path.join("profiles", "r1f_pmc.json")
+PMC_PROFILE = os.path.join("profiles", "r3_pmc.json")
+PMC_FALLBACK = os.path.join("profiles", "r2_pmc.json")
 N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMDs
 CLK_HZ = 2.4e9                 # nominal shader clock (the chip may hold less under load; stated, not measured)
 VALU_CYCLES = 4.0              # a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU counts
@@ -89,6 +89,9 @@ def parse_args(argv=None):
                     help="single process: march only shard 0 of G of the strong-scaling ray set (what ONE rank of a G-GPU "
                          "run does, without the all-reduce) -- per-shard timings for the scaling projection in DESIGN.md")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the `variants` leg (the reference's six rotated views and the shifted plane source)")
+    ap.add_argument("--variant-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
                                                         "to rehearse the multi-rank flow on a 1-GPU box)")
     args = ap.parse_args(argv)
@@ -179,6 +182,44 @@ def make_rays(n_rays: int, seed: int):
     return pos, vel
 
 
+def make_rays_shifted(n_rays: int, seed: int):
+    """The headline source moved by a third of a pixel in x and z: the same rays, no longer aligned with the
+    voxel columns (1024 pixels over 255 cells: the headline's 8 x 8-pixel sort tiles sit on 2 x 2 cells)."""
+    pos, vel = make_rays(n_rays, seed)
+    side = int(round(n_rays ** 0.5))
+    pos[:, 0] += 1.0 / side / 3.0
+    pos[:, 2] += 1.0 / side / 3.0
+    pos.clamp_(0.0, 1.0 - 1e-6)
+    pos[:, 1] = 0.0
+    return pos, vel
+
+
+def make_rays_cube6(n_rays: int, seed: int, device):
+    """What the reference's Luneburg experiment feeds the path every iteration (core/luneburg_opt.py:53-57,94):
+    `source.rand_rays_cube((P, P), spp, span, circle=True)` -- six plane views, four about z and two about x
+    (core/source.py:398-412) -- turned by ONE random rotation (`random_rotate_ic`, core/source.py:555-563;
+    scipy Rotation.random with random_state = seed), generated by the package's device generators with the
+    rotation fused.  P is chosen so that the disc-masked views hold a little more than n_rays rays; the first
+    n_rays are kept (the last view loses < 1 %).  Rays start on planes tangent to the inscribed sphere, i.e.
+    partly outside the box, exactly as in the reference."""
+    import numpy as np
+    import torch
+    from scipy.spatial.transform import Rotation
+    from adjointnonlinearraytracing_amd import source
+    rot = torch.from_numpy(Rotation.random(random_state=seed).as_matrix())
+    P = int(np.ceil(np.sqrt(n_rays * 1.004 / (6.0 * np.pi / 4.0))))
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    while True:
+        off = torch.rand(6, 2, P, P, generator=gen)
+        (x, v, planes), nrays = source.rand_rays_cube((P, P), 1, 1.0, circle=True, offset=off, device=device,
+                                                      rotmat=rot, span=1.0)
+        if x.shape[0] >= n_rays:
+            break
+        P += 2
+    return x[:n_rays].contiguous(), v[:n_rays].contiguous(), {"pixels_per_view": P, "rays_per_view": nrays,
+                                                              "rotation_seed": seed}
+
+
 def make_workload(R: int, n_rays: int, device, seed: int):
     """Luneburg ball on an R^3 grid + the plane source above (kept for tools/ and tests)."""
     span = 1.0
@@ -205,7 +246,7 @@ def pmc_kernel(pmc, *prefixes):
     if not pmc:
         return None
     for prefix in prefixes:
-        hits = [v for k, v in pmc.items() if k.startswith(prefix)]
+        hits = [v for k, v in pmc.items() if k.startswith(prefix) and isinstance(v, dict)]
         if hits:      # several instantiations may be launched (one returns at once): the one that did the work
             return max(hits, key=lambda v: v.get("SQ_INSTS_VALU", 0.0))
     return None
@@ -242,9 +283,13 @@ def physical_bound(pk, ms):
     return out
 
 
-def cpu_baseline(R, h, ds, rif_np, pos_np, vel_np, target_seconds=15.0):
+def cpu_baseline(R, h, ds, rif_np, pos_np, vel_np, target_seconds=15.0, gpu=None):
     """Time the CPU oracle (kind 'port': plain-C restatement of the reference, single thread --
-    the reference's CPU path is single-threaded) on a ray sub-sample."""
+    the reference's CPU path is single-threaded) on a ray sub-sample.
+
+    gpu = (callable rays -> dict(xt, vt, grad, fwd_steps, adj_steps)) runs the benchmark's OWN kernel configuration on
+    a given ray sub-set; when given, the all-cores run of the oracle (factored arithmetic = the op sequence of the
+    kernels) doubles as the checker: -> (cpu_baseline, parity_check)."""
     import numpy as np
     from oracle import oracle as O
     O.build()
@@ -266,18 +311,42 @@ def cpu_baseline(R, h, ds, rif_np, pos_np, vel_np, target_seconds=15.0):
     # what a maintainer would get from the host without a GPU; reported beside the 1-thread figure.
     threads = max(1, min(len(os.sched_getaffinity(0)), 32))
     n_all = int(min(len(pos_np), n * max(1, threads // 2)))
-    sel_all = np.linspace(0, len(pos_np) - 1, n_all).astype(np.int64)
-    a = O.bench_allcores(rif_np, (R, R, R), pos_np[sel_all], vel_np[sel_all], h, ds, threads)
+    if n_all * 10 >= len(pos_np) * 9:
+        n_all = len(pos_np)                     # close to the whole workload: take all of it (parity at full size)
+    sel_all = np.arange(len(pos_np)) if n_all == len(pos_np) else np.linspace(0, len(pos_np) - 1, n_all).astype(np.int64)
+    with O.arith("factored"):
+        a = O.bench_allcores(rif_np, (R, R, R), pos_np[sel_all], vel_np[sel_all], h, ds, threads, want_rays=gpu is not None)
     allcores = {"value": a["fwd_steps"] / (a["t_fwd"] + a["t_adj"]), "unit": "ray-steps/s", "cores": a["threads"],
                 "sample": f"{n_all} rays, fwd {a['t_fwd']:.2f}s + adjoint {a['t_adj']:.2f}s (incl. summing "
-                          f"{a['threads']} private grids)"}
-    return {
+                          f"{a['threads']} private grids), factored fp32 arithmetic"}
+    base = {
         "allcores": allcores,
         "value": steps / (t2 - t0), "unit": "ray-steps/s", "cores": 1, "kind": "port",
         "sample": f"{n} of the workload's rays (evenly strided), {R}^3 grid, fwd {t1 - t0:.2f}s + adjoint {t2 - t1:.2f}s, "
                   f"{steps} fwd ray-steps",
         "fwd_ray_steps_per_s": steps / (t1 - t0), "adj_ray_steps_per_s": b["steps_total"] / (t2 - t1),
     }
+    if gpu is None:
+        return base, None
+    g = gpu(sel_all)
+    gn = float(np.linalg.norm(a["grad"].astype(np.float64)))
+    parity = {
+        "checker": "oracle/ (plain-C restatement of src/tracer.cpp:35-100,384-440), factored fp32 arithmetic, all host "
+                   "cores over contiguous ray chunks, private grids summed",
+        "rays": int(n_all), "full_workload": bool(n_all == len(pos_np)),
+        "kernel_flags": g["flags_note"],
+        "xt_bit_exact": bool(np.array_equal(g["xt"], a["xt"])), "vt_bit_exact": bool(np.array_equal(g["vt"], a["vt"])),
+        "rays_differing": int(np.count_nonzero(np.any(g["xt"] != a["xt"], axis=1) | np.any(g["vt"] != a["vt"], axis=1))),
+        "fwd_ray_steps_gpu": int(g["fwd_steps"]), "fwd_ray_steps_oracle": int(a["fwd_steps"]),
+        "adj_ray_steps_gpu": int(g["adj_steps"]), "adj_ray_steps_oracle": int(a["adj_steps"]),
+        "rel_l2": float(np.linalg.norm(g["grad"].astype(np.float64) - a["grad"].astype(np.float64)) / max(gn, 1e-300)),
+        "rel_l2_bound": 2e-5,
+    }
+    parity["ok"] = bool(parity["xt_bit_exact"] and parity["vt_bit_exact"]
+                        and parity["fwd_ray_steps_gpu"] == parity["fwd_ray_steps_oracle"]
+                        and parity["adj_ray_steps_gpu"] == parity["adj_ray_steps_oracle"]
+                        and parity["rel_l2"] <= parity["rel_l2_bound"])
+    return base, parity
 
 
 def run_rank(args) -> int:
@@ -356,24 +425,17 @@ def run_rank(args) -> int:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run_mode(mode):
-        """-> dict of this rank's measurements for one scaling mode."""
-        if mode == "strong":
-            gpos, gvel = make_rays(args.rays, seed=0)              # the metric's single ray set, same on every rank
-            lo, hi = drrt_dist.shard_bounds(args.rays, rank, world)
-            if args.shard_of > 1 and world == 1:
-                lo, hi = drrt_dist.shard_bounds(args.rays, 0, args.shard_of)
-            pos, vel = gpos[lo:hi].contiguous().to(dev), gvel[lo:hi].contiguous().to(dev)
-        else:
-            pos, vel = (t.to(dev) for t in make_rays(args.rays, seed=rank))
+    def bench_rays(pos, vel, steps, warmup, force_flags=None, keep=False):
+        """Time `steps` fwd + adjoint passes over the rays (pos, vel) resident on the device; -> this rank's measurements.
+        force_flags = (fflags, aflags, pair) overrides the pair-copy rule (parity runs on a sub-sample keep the flags)."""
         n = pos.shape[0]
-        fflags, aflags, pair = pair_flags(n)
-        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, nvox, fflags)) + 1024, dtype=torch.uint8, device=dev)
+        fflags, aflags, pair = force_flags if force_flags is not None else pair_flags(n)
+        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, nvox, fflags | aflags)) + 1024, dtype=torch.uint8, device=dev)
         xt, vt = torch.empty_like(pos), torch.empty_like(vel)
         dx, dv = torch.ones_like(pos), torch.ones_like(vel)          # adjoint seed dx=dv=1 (src/test.cpp:142-144)
         st_f = torch.zeros(3, dtype=torch.int64, device=dev)
         st_a = torch.zeros(3, dtype=torch.int64, device=dev)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
         def step(k=None):
             _lib.check(lib.drrt_trace_f32(p(rif), nvox, res, n, p(pos), p(vel), h, ds, p(xt), p(vt),
@@ -389,12 +451,12 @@ def run_rank(args) -> int:
                 if k is not None:
                     ev[k][1].record()
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         barrier()
-        _lib.check(lib.drrt_profile_begin(8 * args.steps + 8))
+        _lib.check(lib.drrt_profile_begin(8 * steps + 8))
         t0 = time.perf_counter()
-        for k in range(args.steps):
+        for k in range(steps):
             step(k)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -402,6 +464,7 @@ def run_rank(args) -> int:
         lib.drrt_profile_end()
         ms_ar = (sum(a.elapsed_time(b) for a, b in ev) / len(ev)) if use_dist else 0.0
 
+        dbg = None
         if args.debug_counters:
             off = (ws.numel() - 512) & ~7
             dbg = ws[off:off + 512].view(torch.int64).cpu().tolist()
@@ -422,10 +485,65 @@ def run_rank(args) -> int:
         def avg(name):
             v = [ms for k, ms in prof if k == name]
             return (sum(v) / len(v)) if v else float("nan")
-        return dict(mode=mode, n=n, elapsed=elapsed, fwd_total=fwd_total, adj_total=adj_total, fwd_steps=fwd_steps,
-                    adj_steps=adj_steps, n_failed=n_failed, ms_fwd=avg("trace"), ms_adj=avg("backtrace"),
-                    ms_sort=avg("sort"), ms_zero=avg("zero"), ms_quad=avg("quad"), ms_allreduce=ms_ar, pair=pair,
-                    pos=pos, vel=vel)
+        out = dict(n=n, steps=steps, elapsed=elapsed, fwd_total=fwd_total, adj_total=adj_total, fwd_steps=fwd_steps,
+                   adj_steps=adj_steps, n_failed=n_failed, ms_fwd=avg("trace"), ms_adj=avg("backtrace"),
+                   ms_sort=avg("sort"), ms_zero=avg("zero"), ms_quad=avg("quad"), ms_allreduce=ms_ar, pair=pair,
+                   pos=pos, vel=vel, flags=(fflags, aflags, pair), dbg=dbg)
+        if keep:                                   # results of the LAST step (the adjoint's grid holds this rank's gradient
+            out.update(xt=xt, vt=vt,               # only when there is no all-reduce: parity_check runs at world == 1)
+                       grad=grad.clone())
+        return out
+
+    def direct_atomics_grad(m):
+        """dL/dn of the rays of measurement `m` (its exit rays `xt`, `vt`, dx = dv = 1) by the one-atomic-per-tap kernel:
+        no windows, no register accumulators, no visit order -- the in-library cross-check of the windowed adjoint."""
+        n = m["pos"].shape[0]
+        g = torch.empty(nvox, dtype=torch.float32, device=dev)
+        ones = torch.ones_like(m["xt"])
+        _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(m["xt"]), p(m["vt"]), p(ones), p(ones), h, ds, p(g),
+                                          None, None, 0, _lib.FLAG_DIRECT_ATOMICS, stream))
+        torch.cuda.synchronize(dev)
+        return g
+
+    def rel_l2(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+    def run_mode(mode):
+        """-> dict of this rank's measurements for one scaling mode."""
+        if mode == "strong":
+            gpos, gvel = make_rays(args.rays, seed=0)              # the metric's single ray set, same on every rank
+            lo, hi = drrt_dist.shard_bounds(args.rays, rank, world)
+            if args.shard_of > 1 and world == 1:
+                lo, hi = drrt_dist.shard_bounds(args.rays, 0, args.shard_of)
+            pos, vel = gpos[lo:hi].contiguous().to(dev), gvel[lo:hi].contiguous().to(dev)
+        else:
+            pos, vel = (t.to(dev) for t in make_rays(args.rays, seed=rank))
+        out = bench_rays(pos, vel, args.steps, args.warmup, keep=(world == 1 and mode == "strong"))
+        out["mode"] = mode
+        return out
+
+    def run_variant(name):
+        """The other ray distributions of SURVEY 8.6 on the same grid (1 GPU; after the headline run, not part of `value`)."""
+        if name == "plane_shifted":
+            pos, vel = (t.to(dev) for t in make_rays_shifted(args.rays, seed=0))
+            meta = {"rays": "the headline's plane source moved by 1/3 pixel in x and z"}
+        else:
+            pos, vel, info = make_rays_cube6(args.rays, 0, dev)
+            meta = {"rays": "source.rand_rays_cube((P, P), 1, span, circle=True) + random_rotate_ic "
+                            "(core/source.py:398-412,555-563; core/luneburg_opt.py:53-57), device generators, first "
+                            f"{args.rays} rays", **info}
+        v = bench_rays(pos, vel, args.variant_steps, 2, keep=True)
+        g_ref = direct_atomics_grad(v)
+        fl = v["flags"]
+        res_ = {"n_rays": v["n"], "steps": v["steps"], "ms_per_step": v["elapsed"] / v["steps"] * 1e3,
+                "trace": v["ms_fwd"], "backtrace": v["ms_adj"], "sort": v["ms_sort"],
+                "fwd_ray_steps": v["fwd_steps"], "adj_ray_steps": v["adj_steps"], "n_failed": v["n_failed"],
+                "value": v["fwd_steps"] * v["steps"] / v["elapsed"],
+                "fwd_ns_per_ray_step": v["ms_fwd"] * 1e6 / max(v["fwd_steps"], 1),
+                "adj_ns_per_ray_step": v["ms_adj"] * 1e6 / max(v["adj_steps"], 1),
+                "pair_grid": bool(fl[2]), "grad_rel_l2_vs_direct_atomics": rel_l2(v["grad"], g_ref)}
+        res_.update(meta)
+        return res_
 
     modes = ["strong", "weak"] if args.scaling == "both" else [args.scaling]
     results = {m: run_mode(m) for m in modes}
@@ -445,13 +563,21 @@ def run_rank(args) -> int:
         pk_fwd = pmc_kernel(pmc, "drrt::k_trace_flat", "drrt::k_trace<0>")
         tr_adj = pk_adj and pk_adj.get("hbm_traffic_bytes_per_launch")
         tr_fwd = pk_fwd and pk_fwd.get("hbm_traffic_bytes_per_launch")
-        src_note = (f"{pmc_src}: rocprofv3 --pmc passes of this command, committed; read from that file, NOT "
+        lib_version = lib.drrt_version().decode()
+        pmc_lib = ((pmc or {}).get("_meta") or {}).get("lib_version")
+        pmc_stale = bool(pmc_src) and pmc_lib != lib_version
+        if pmc_stale:
+            print(f"bench.py: WARNING: {pmc_src} was recorded with library '{pmc_lib}', this run uses '{lib_version}': the "
+                  f"PMC-derived fields (traffic, physical_bound) describe OTHER kernels; re-run tools/profile_bench.sh",
+                  file=sys.stderr)
+        src_note = (f"{pmc_src} (recorded with library '{pmc_lib}'{'; STALE: this run uses ' + repr(lib_version) if pmc_stale else ''}): "
+                    f"rocprofv3 --pmc passes of this command, committed; read from that file, NOT "
                     f"measured in this run") if pmc_src else None
         shard = (f"the metric's single set of {args.rays} rays split into {world} contiguous shards "
                  f"({n} on rank 0)") if main_mode == "strong" else f"{n} rays per GPU (own seed per rank)"
         roof = {"bound": "hbm", "kernel": "adjoint march (k_backtrace_flat)", "achieved": ach_adj,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_adj / HBM_PEAK_GBS, "traffic": tr_adj,
-                "traffic_source": src_note, "pmc_source": pmc_src,
+                "traffic_source": src_note, "pmc_source": pmc_src, "pmc_lib_version": pmc_lib, "pmc_stale": pmc_stale,
                 "hbm_measured_gbps": (tr_adj / (ms_adj * 1e-3) / 1e9) if tr_adj else None,
                 "algorithmic_bytes_per_ray_step": B_ADJ, "ray_steps_per_launch": adj_steps, "avg_kernel_ms": ms_adj}
         roof.update(physical_bound(pk_adj, ms_adj))
@@ -469,7 +595,7 @@ def run_rank(args) -> int:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": m["elapsed"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": main_mode, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "lib_version": lib_version,
             "config": {"workload": f"Luneburg ball {R}^3 fp32 grid (replicated), {shard} from a seeded jittered "
                                    f"plane source on the y=0 face, ds=h/2, fwd trace + adjoint backtrace (dx=dv=1)"
                                    + (", one all-reduce(sum) of the dL/dn grid per step "
@@ -493,9 +619,35 @@ def run_rank(args) -> int:
                                    "ms_per_step": w["elapsed"] / args.steps * 1e3, "rays_per_gpu": w["n"],
                                    "phase_ms": {"sort_avg": w["ms_sort"], "trace": w["ms_fwd"], "backtrace": w["ms_adj"],
                                                 "allreduce": w["ms_allreduce"] if use_dist else None}}
+        if world == 1 and not args.no_variants and not args.shard_of:
+            base_ns = ms_adj * 1e6 / max(adj_steps, 1)
+            out["variants"] = {"headline_adj_ns_per_ray_step": base_ns,
+                               "headline_fwd_ns_per_ray_step": ms_fwd * 1e6 / max(fwd_steps, 1)}
+            for name in ("cube6_rotated", "plane_shifted"):
+                v = run_variant(name)
+                v["adj_ns_ratio_to_headline"] = v["adj_ns_per_ray_step"] / base_ns
+                out["variants"][name] = v
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(R, h, ds, rif.cpu().numpy(), m["pos"].cpu().numpy(), m["vel"].cpu().numpy(),
-                                               target_seconds=args.cpu_seconds)
+            def gpu_subset(sel):
+                """The benchmark's own kernel configuration (same flags as the timed run) on the rays `sel`."""
+                import numpy as np
+                fl = m["flags"]
+                note = (f"fwd 0x{fl[0]:x} adj 0x{fl[1]:x} (sort + order hand-over, pair copy "
+                        f"{'built by the forward, reused by the adjoint' if fl[2] else 'off'})")
+                if len(sel) == m["n"]:
+                    r = m                                      # the timed run's last step IS the result
+                else:
+                    idx = torch.from_numpy(np.asarray(sel)).to(dev)
+                    r = bench_rays(m["pos"][idx].contiguous(), m["vel"][idx].contiguous(), 1, 0, force_flags=fl, keep=True)
+                return {"xt": r["xt"].cpu().numpy(), "vt": r["vt"].cpu().numpy(), "grad": r["grad"].cpu().numpy(),
+                        "fwd_steps": r["fwd_steps"], "adj_steps": r["adj_steps"], "flags_note": note}
+            base, parity = cpu_baseline(R, h, ds, rif.cpu().numpy(), m["pos"].cpu().numpy(), m["vel"].cpu().numpy(),
+                                        target_seconds=args.cpu_seconds, gpu=gpu_subset if "xt" in m else None)
+            out["cpu_baseline"] = base
+            if parity is not None:
+                out["parity_check"] = parity
+                if not parity["ok"]:
+                    print("bench.py: PARITY CHECK FAILED: " + json.dumps(parity), file=sys.stderr)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

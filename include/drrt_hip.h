@@ -132,7 +132,8 @@ DRRT_API size_t drrt_workspace_bytes_grid(size_t n, long long nvox, unsigned fla
 /* Message of the last error on this thread ("" if none). */
 DRRT_API const char* drrt_last_error(void);
 
-/* Library / build identification, e.g. "drrt_hip 0.1 gfx950". */
+/* Library / build identification: "drrt_hip <abi> gfx950 src:<12 hex digits>", the digest being that of the sources
+ * the library was built from (csrc/Makefile); profiles/ *_pmc.json record it so that a stale profile is detectable. */
 DRRT_API const char* drrt_version(void);
 
 /* ---- visit order hand-over (optimisation hint; with a valid permutation results do not depend on it) ---

@@ -193,10 +193,12 @@ DEFINE_API(double, f64)
 #endif
 EXPORT int oracle_bench_allcores_f32(const float* rif, const int* res, long long nvox, size_t n,
     const float* pos, const float* vel, float h, float ds, int nthreads, float* grad_out,
-    double* t_fwd, double* t_adj, long long* fwd_steps, int* threads_used) {
+    double* t_fwd, double* t_adj, long long* fwd_steps, int* threads_used,
+    float* xt_out, float* vt_out, int* steps_out, long long* adj_steps) {
 #ifndef _OPENMP
   (void)rif; (void)res; (void)nvox; (void)n; (void)pos; (void)vel; (void)h; (void)ds; (void)nthreads;
   (void)grad_out; (void)t_fwd; (void)t_adj; (void)fwd_steps; (void)threads_used;
+  (void)xt_out; (void)vt_out; (void)steps_out; (void)adj_steps;
   return -9;
 #else
   if (nthreads < 1) nthreads = omp_get_max_threads();
@@ -219,13 +221,15 @@ EXPORT int oracle_bench_allcores_f32(const float* rif, const int* res, long long
   }
   double t1 = omp_get_wtime();
   int used = 0;
-#pragma omp parallel num_threads(nthreads) reduction(|:rc_all)
+  long long ast = 0;
+#pragma omp parallel num_threads(nthreads) reduction(|:rc_all) reduction(+:ast)
   {
     int t = omp_get_thread_num(), T = omp_get_num_threads();
     size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
-    long long st;
+    long long st = 0;
     rc_all |= oracle_backtrace_f32(rif, res, nvox, hi - lo, xt + 3 * lo, vt + 3 * lo, ones + 3 * lo, ones + 3 * lo,
                                    h, ds, 1.0f, grads + (size_t)t * (size_t)nvox, &st);
+    ast += st;
 #pragma omp single
     used = T;
   }
@@ -241,6 +245,10 @@ EXPORT int oracle_bench_allcores_f32(const float* rif, const int* res, long long
   long long fs = 0;
   for (size_t i = 0; i < n; ++i) fs += steps[i];
   *t_fwd = t1 - t0; *t_adj = t2 - t1; *fwd_steps = fs; *threads_used = used;
+  if (adj_steps) *adj_steps = ast;
+  if (xt_out) memcpy(xt_out, xt, sizeof(float) * 3 * n);
+  if (vt_out) memcpy(vt_out, vt, sizeof(float) * 3 * n);
+  if (steps_out) memcpy(steps_out, steps, sizeof(int) * n);
   free(xt); free(vt); free(ones); free(steps); free(grads);
   return rc_all;
 #endif

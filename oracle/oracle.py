@@ -235,19 +235,29 @@ def backtrace_cable(rif, radius, length, xt, vt, dx, dv, ds, dtype=np.float32):
     return dict(grad=grad, steps_total=st.value)
 
 
-def bench_allcores(rif, res, pos, vel, h, ds, nthreads=0):
+def bench_allcores(rif, res, pos, vel, h, ds, nthreads=0, want_rays=False):
     """Timing harness: fp32 trace + backtrace(dx=dv=1) over contiguous ray chunks on `nthreads` OpenMP
-    threads (0 = all), private gradient grids summed at the end.  Returns dict(t_fwd, t_adj, fwd_steps,
-    threads, grad)."""
+    threads (0 = all), private gradient grids summed at the end.  Runs in the arithmetic mode that is
+    selected (``arith``).  Returns dict(t_fwd, t_adj, fwd_steps, adj_steps, threads, grad) and, with
+    ``want_rays``, the exit rays ``xt``, ``vt`` and the per-ray forward step counts ``steps`` -- what
+    bench.py's ``parity_check`` compares the GPU's results of the SAME rays with."""
     rif = _c(np.asarray(rif).reshape(-1), np.float32)
     pos, vel = _c(pos, np.float32, 3), _c(vel, np.float32, 3)
     grad = np.zeros(rif.size, np.float32)
-    tf, ta, fs, th = C.c_double(0), C.c_double(0), C.c_longlong(0), C.c_int(0)
-    rc = lib().oracle_bench_allcores_f32(_p(rif), _p(_res(res)), C.c_longlong(rif.size), C.c_size_t(len(pos)), _p(pos),
+    n = len(pos)
+    xt = np.empty((n, 3), np.float32) if want_rays else None
+    vt = np.empty((n, 3), np.float32) if want_rays else None
+    steps = np.empty(n, np.int32) if want_rays else None
+    tf, ta, fs, th, ast = C.c_double(0), C.c_double(0), C.c_longlong(0), C.c_int(0), C.c_longlong(0)
+    rc = lib().oracle_bench_allcores_f32(_p(rif), _p(_res(res)), C.c_longlong(rif.size), C.c_size_t(n), _p(pos),
                                          _p(vel), C.c_float(h), C.c_float(ds), C.c_int(nthreads), _p(grad),
-                                         C.byref(tf), C.byref(ta), C.byref(fs), C.byref(th))
+                                         C.byref(tf), C.byref(ta), C.byref(fs), C.byref(th),
+                                         _p(xt), _p(vt), _p(steps), C.byref(ast))
     _check(rc)
-    return dict(t_fwd=tf.value, t_adj=ta.value, fwd_steps=fs.value, threads=th.value, grad=grad)
+    out = dict(t_fwd=tf.value, t_adj=ta.value, fwd_steps=fs.value, adj_steps=ast.value, threads=th.value, grad=grad)
+    if want_rays:
+        out.update(xt=xt, vt=vt, steps=steps)
+    return out
 
 
 # ----------------------------------------------------------------------------- samplers

@@ -39,6 +39,12 @@ helpers -- plus the CPU oracle:
                        they consume are recorded by replaying the same host-generator seed
                        -> pins the device ray generation
 
+  march_getlinear.npz  the march loop (src/tracer.cpp:66-87) in float64 with (n, grad n) of every sample taken from the
+                       reference's OWN Grid.GetLinear (:227-273, axis-permuted scene) and torch.autograd of a random linear
+                       functional of the exit rays with respect to the scene -> pins Tracer::trace's exit state and
+                       Tracer::backtrace's dL/dn (h = 1 as written; h != 1 with the 1/h correction, Q3) with reference
+                       code inside the loop body
+
 Only DATA is stored (inputs and expected outputs); no reference source text.
 """
 import os
@@ -188,6 +194,63 @@ def ad_vs_adjoint():
                     f"{tag}_vt": vt.detach().numpy(), f"{tag}_gx": gx.numpy(), f"{tag}_gv": gv.numpy(),
                     f"{tag}_ad_grad": rr.grad.numpy()})
     save("ad_vs_adjoint.npz", **out)
+
+
+def march_getlinear():
+    """Symplectic-Euler march (src/tracer.cpp:66-87: masked sample, v += ds n grad n, x += ds v, box tests, exit record,
+    global loop until every ray has escaped) in float64 where the sample (n, grad n) of every step comes from the
+    reference's own trilinear interpolant Grid.GetLinear RUN AS IS on the axis-permuted scene (Q2), followed by
+    torch.autograd of L = sum(cx . xt) + sum(cv . vt) with respect to the scene.  Rays start a fraction of a step in
+    front of the y = 0 face (the reference's sources start on or outside the box; Tracer::backtrace re-marches until the
+    ray leaves the box, so it is the adjoint of rays that ENTER it) and are only ever sampled in bounds (Q4), where
+    GetLinear's extra weight clip is the identity."""
+    out = {}
+    for tag, R, h, seed in (("h1", 13, 1.0, 21), ("h04", 17, 0.4, 22), ("h1b", 9, 1.0, 23)):
+        torch.manual_seed(seed)
+        ds = 0.37 * h                                                  # incommensurate with the cell size: no face ties
+        g1 = torch.linspace(-1.0, 1.0, R, dtype=torch.float64)
+        Z, Y, X = torch.meshgrid(g1, g1, g1, indexing="ij")           # OUR layout scene[z, y, x]
+        scene = 1.2 + 0.25 * torch.exp(-2.5 * ((X - 0.1) ** 2 + (Y + 0.2) ** 2 + Z ** 2)) \
+            + 0.04 * torch.rand(R, R, R, dtype=torch.float64)
+        N = 160
+        pos = torch.rand(N, 3, dtype=torch.float64) * (R - 3) * h + h  # at least one cell away from every face
+        pos[:, 1] = -(0.1 + 0.8 * torch.rand(N, dtype=torch.float64)) * ds * 1.2 * 0.9   # enters the box with its first step
+        vel = torch.randn(N, 3, dtype=torch.float64) * 0.25
+        vel[:, 1] = 1.0
+        vel = vel / vel.norm(dim=1, keepdim=True) * 1.2
+        rr = scene.clone().requires_grad_(True)
+        G = ref_grid.Grid(rr.permute(2, 1, 0), h)                      # reference layout scene[x, y, z]; a VIEW of rr
+        shape = (R, R, R)
+        max_steps = int(4 * h * R / ds)                                # src/tracer.cpp:51
+        x, v = pos.clone(), vel.clone()
+        xt, vt = pos.clone(), vel.clone()                              # :56-57
+        inside = TA.inbounds(shape, h, x)                              # :61
+        esc = torch.zeros_like(inside)
+        iters = 0
+        for _ in range(max_steps):
+            n = torch.zeros(N, dtype=torch.float64); g = torch.zeros(N, 3, dtype=torch.float64)
+            if bool(inside.any()):
+                f_, fx_ = G.GetLinear(x[inside])                       # the reference's interpolant, as is
+                n = n.index_put((inside.nonzero().squeeze(1),), f_)
+                g = g.index_put((inside.nonzero().squeeze(1),), fx_)
+            v = v + (ds * n)[:, None] * g                              # :70
+            x = x + ds * v                                             # :71
+            cur = TA.inbounds(shape, h, x)                             # :73
+            cross = inside & ~cur                                      # :74
+            esc = esc | cross | TA.escaped(shape, h, x, v)             # :75-76
+            xt = torch.where(cross[:, None], x, xt); vt = torch.where(cross[:, None], v, vt)   # :79-80
+            iters += 1
+            if bool(esc.all()):                                        # :82
+                break
+            inside = cur                                               # :86
+        assert bool(esc.all()), "golden march: a ray did not escape"
+        cx, cv = torch.randn(N, 3, dtype=torch.float64), torch.randn(N, 3, dtype=torch.float64)
+        ((xt * cx).sum() + (vt * cv).sum()).backward()
+        out.update({f"{tag}_scene": scene.numpy(), f"{tag}_h": h, f"{tag}_ds": ds, f"{tag}_pos": pos.numpy(),
+                    f"{tag}_vel": vel.numpy(), f"{tag}_xt": xt.detach().numpy(), f"{tag}_vt": vt.detach().numpy(),
+                    f"{tag}_cx": cx.numpy(), f"{tag}_cv": cv.numpy(), f"{tag}_grad": rr.grad.numpy(),
+                    f"{tag}_iters": iters})
+    save("march_getlinear.npz", **out)
 
 
 def fuel_injection():
@@ -439,6 +502,7 @@ if __name__ == "__main__":
         sys.exit(0)
     splat_linear()
     hessians_by_autograd()
+    march_getlinear()
     getlinear_grid()
     getlinear_cable()
     luneburg_cube()

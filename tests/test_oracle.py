@@ -114,6 +114,33 @@ def test_adjoint_is_exact_discrete_adjoint(oracle, tag):
             assert 0.3 < cases.rel_l2(written, ad) < 0.7
 
 
+@pytest.mark.parametrize("tag", ["h1", "h04", "h1b"])
+def test_march_with_the_references_getlinear(oracle, tag):
+    """The march loop with the reference's OWN interpolant in its body: tests/golden/make_golden.py::march_getlinear steps
+    160 interior rays in float64 with (n, grad n) from core/grid.py Grid.GetLinear (:227-273) RUN AS IS and takes
+    torch.autograd of a random linear functional of the exit rays w.r.t. the scene.  The oracle's Tracer::trace must land
+    on the same exit samples and Tracer::backtrace on the same dL/dn -- as written for h = 1, with the 1/h correction for
+    h != 1 (Q3) -- in both arithmetic modes.  Pins src/tracer.cpp:68-71 and :420-435 with reference code in the loop."""
+    z = load("march_getlinear.npz")
+    scene = z[f"{tag}_scene"]
+    h, ds = float(z[f"{tag}_h"]), float(z[f"{tag}_ds"])
+    for mode in ("literal", "factored"):
+        with oracle.arith(mode):
+            o = oracle.trace(scene, scene.shape, z[f"{tag}_pos"], z[f"{tag}_vel"], h, ds, dtype=np.float64)
+            assert o["n_failed"] == 0 and o["iters"] == int(z[f"{tag}_iters"])
+            assert np.abs(o["xt"] - z[f"{tag}_xt"]).max() < 1e-10 and np.abs(o["vt"] - z[f"{tag}_vt"]).max() < 1e-10
+            exact = oracle.backtrace(scene, scene.shape, z[f"{tag}_xt"], z[f"{tag}_vt"], z[f"{tag}_cx"], z[f"{tag}_cv"], h, ds,
+                                     dtype=np.float64, corrected_h=True)["grad"]
+            written = oracle.backtrace(scene, scene.shape, z[f"{tag}_xt"], z[f"{tag}_vt"], z[f"{tag}_cx"], z[f"{tag}_cv"], h, ds,
+                                       dtype=np.float64, corrected_h=False)["grad"]
+        ad = z[f"{tag}_grad"].reshape(-1)
+        assert cases.rel_l2(exact, ad) < 1e-10
+        if h == 1.0:
+            assert cases.rel_l2(written, ad) < 1e-10          # as written == exact discrete adjoint at h = 1
+        else:
+            assert cases.rel_l2(written, ad) > 0.1            # Q3: the gradient splat lacks 1/h
+
+
 def _plane_loss_np(xt, vt, planes, span):
     """core/sensor.py:195-202 trace_rays_to_plane + core/luneburg_opt.py:100-102 loss, in numpy."""
     sp, sn = planes[:, 0, :].astype(np.float64), planes[:, 1, :].astype(np.float64)
