@@ -31,6 +31,7 @@ FLAG_LEGACY_ADJOINT = 0x80000
 FLAG_LEGACY_FORWARD = 0x100000
 FLAG_Q16_POS_ONLY = 0x200000
 FLAG_STATIC_WINDOW = 0x400000
+FLAG_CHORD_KEY = 0x800000
 ADAM_MASK_BOUNDARY, ADAM_CLAMP_MIN = 1, 2
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4

@@ -1683,7 +1683,7 @@ namespace drrt {
 size_t sort_workspace_bytes(size_t n);
 hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void* pos, const void* vel, int io_half,
                                     float dir_sign, void* ws, size_t ws_bytes, const uint32_t** perm_out,
-                                    hipStream_t stream);
+                                    hipStream_t stream, bool chord_key);
 }
 
 static thread_local char g_err[512] = "";
@@ -1872,7 +1872,8 @@ static int maybe_sort(const Vol& V, float h, size_t n, const void* pos, const vo
   if (!(flags & DRRT_FLAG_SORT_RAYS) || n < 2) return DRRT_OK;
   if (!ws || ws_bytes < sort_workspace_bytes(n)) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_SORT_RAYS");
   ProfScope prof(DRRT_PROF_SORT, s);
-  hipError_t e = sort_rays_by_entry_voxel(V, h, n, pos, vel, io_half, dir_sign, ws, ws_bytes, perm, s);
+  hipError_t e = sort_rays_by_entry_voxel(V, h, n, pos, vel, io_half, dir_sign, ws, ws_bytes, perm, s,
+                                          (flags & DRRT_FLAG_CHORD_KEY) != 0);
   if (e == hipSuccess) { g_last_order = *perm; g_last_order_n = n; }
   return e == hipSuccess ? DRRT_OK : fail_hip(e, "sort_rays_by_entry_voxel");
 }

@@ -1,21 +1,29 @@
-// drrt_sort.hip -- locality sort of rays by entry voxel (device side, rocPRIM radix sort).
+// drrt_sort.hip -- locality sort of rays (device side, rocPRIM radix sort).
 //
 // Not part of the reference (enoki processes rays in caller order, array-at-a-time); this is the
 // MI355X-side answer to SURVEY.md section 7 step 5: the 64 rays of a wave should stay spatially
 // close for their WHOLE march, so that each of the 8 taps of a wave-step hits a handful of 128-B
 // lines and the adjoint's scatter targets fall into the wave's LDS gradient window.
 //
-// Key = 60-bit "light-field Z-order": the straight line through the ray (from where it meets the
-// grid box along its march direction to where that line leaves the box again) is described by its
-// two end points, each quantised to 10 bits per axis, and the 6 coordinates are bit-interleaved
-// (Morton order in 6-D).  Consecutive keys are therefore close at BOTH ends of the chord:
-//   * plane sources: both end points form 2-D patches  -> compact ray bundles;
-//   * the adjoint of a focusing lens starts with thousands of rays in ONE voxel pointing in
-//     different directions: the far end of the chord separates them by direction;
-//   * point / cone sources: the near end is degenerate, the far end orders the fan.
-// (A key on the start voxel alone -- the first version -- left 27 % of the adjoint's taps outside
-// the LDS windows on the Luneburg benchmark: strips of rays on the side faces fan out.  Re-measured
-// with the final kernels: forward 1.65 vs 1.53 ms, adjoint 6.39 vs 5.99 ms in favour of this key.)
+// Round 3 key ("light-field key", the default): a ray is the line it travels on, i.e. a direction and a 2-D offset in the
+// plane perpendicular to it.
+//   direction  octahedral map of the unit direction, cut into 33 x 33 cells (an ODD count: +-x, +-y, +z are cell CENTRES);
+//              the cell index is the major part of the key, so a collimated view is one contiguous key range;
+//   offset     the point of the line closest to the box centre, in the orthonormal frame (t1, t2) of the CELL's centre
+//              direction (every ray of a cell uses the same frame), scaled by a power of two of the box extent and cut
+//              into 2048 x 2048 cells; the minor part of the key is the HILBERT index of that cell.
+// Why Hilbert and not the Z-order interleave of rounds 1-2: 64 consecutive rays of a Z-order are an aligned 8 x 8 tile only
+// when the sampling grid happens to be aligned with the key cells (the metric's pixel-aligned plane source); shift the
+// same source by a third of a pixel and 11 % of the bundles straddle two far-apart tiles (measured: adjoint 4.8 -> 7.1 ms),
+// and the views of core/source.py rand_rays_cube + random_rotate_ic, oblique to every axis, gave bundles whose box of grid
+// cells was 12 cells wide in the median (82 % wider than the 9^3 window; adjoint 4.8 -> 20 ms: global-atomic fallback).  Any
+// 64 consecutive cells of a Hilbert curve are a connected, compact patch; aligned 8 x 8 blocks are still contiguous, so the
+// aligned source keeps its perfect tiles (tools/bundle_stats.py: offline comparison of the keys).  For the axis-aligned
+// frame the power-of-two scale keeps pixel boundaries on key-cell boundaries.
+//
+// Rounds 1-2 key (DRRT_FLAG_CHORD_KEY, kept for A-B): 60-bit "light-field Z-order": the straight line through the ray
+// (from where it meets the grid box along its march direction to where that line leaves the box again) is described by
+// its two end points, each quantised to 10 bits per axis, and the 6 coordinates are bit-interleaved (Morton order in 6-D).
 // For the adjoint the march direction is -vt and the "start" is the recorded exit sample xt.
 // The permutation only changes the VISIT order; results are written back in the caller's ray order.
 #include <hip/hip_runtime.h>
@@ -81,6 +89,80 @@ __global__ void __launch_bounds__(256) k_chord_keys(Vol V, size_t n, const void*
   idx[i] = (uint32_t)i;
 }
 
+// ---- light-field key ---------------------------------------------------------------------------------------------
+constexpr int kDirHalf = 16;                         // direction cells per octahedral axis: 2 * kDirHalf + 1 = 33
+constexpr int kPosBits = 11;                         // offset cells per axis: 2048
+constexpr int kLfKeyBits = 2 * kPosBits + 11;        // 22 + 11 (33 * 33 = 1089 direction cells < 2^11)
+
+__device__ __forceinline__ uint32_t hilbert2(uint32_t x, uint32_t y) {      // x, y < 2^kPosBits
+  uint32_t d = 0;
+#pragma unroll
+  for (int b = kPosBits - 1; b >= 0; --b) {
+    const uint32_t s = 1u << b, rx = (x >> b) & 1u, ry = (y >> b) & 1u;
+    d += s * s * ((3u * rx) ^ ry);
+    if (ry == 0u) {                                  // rotate / reflect the quadrant
+      if (rx == 1u) { x = s - 1u - x; y = s - 1u - y; }
+      const uint32_t t = x; x = y; y = t;
+    }
+    x &= s - 1u; y &= s - 1u;
+  }
+  return d;
+}
+
+__global__ void __launch_bounds__(256) k_lightfield_keys(Vol V, size_t n, const void* __restrict__ pos,
+                                                         const void* __restrict__ vel, int io_half, float dir_sign,
+                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float p[3] = {ldr(V, pos, 3 * i, io_half, true), ldr(V, pos, 3 * i + 1, io_half, true), ldr(V, pos, 3 * i + 2, io_half, true)};
+  float d[3] = {dir_sign * ldr(V, vel, 3 * i, io_half, false), dir_sign * ldr(V, vel, 3 * i + 1, io_half, false),
+                dir_sign * ldr(V, vel, 3 * i + 2, io_half, false)};
+  idx[i] = (uint32_t)i;
+  const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (!(len > 1e-30f) || !(len < 3.0e38f)) { keys[i] = 0; return; }       // a ray at rest (or non-finite): any place will do
+  const float il = 1.f / len;
+  d[0] *= il; d[1] *= il; d[2] *= il;
+  // octahedral map -> cell (a, b) in [-kDirHalf, kDirHalf]^2
+  const float l1 = fabsf(d[0]) + fabsf(d[1]) + fabsf(d[2]);
+  float ox = d[0] / l1, oy = d[1] / l1;
+  if (d[2] < 0.f) {
+    const float fx = (1.f - fabsf(oy)) * (ox >= 0.f ? 1.f : -1.f), fy = (1.f - fabsf(ox)) * (oy >= 0.f ? 1.f : -1.f);
+    ox = fx; oy = fy;
+  }
+  int a = (int)rintf(ox * (float)kDirHalf), b = (int)rintf(oy * (float)kDirHalf);
+  a = a < -kDirHalf ? -kDirHalf : (a > kDirHalf ? kDirHalf : a);
+  b = b < -kDirHalf ? -kDirHalf : (b > kDirHalf ? kDirHalf : b);
+  // centre direction of the cell, and ITS frame: the coordinate axis least aligned with it, made orthogonal
+  float cx = (float)a / (float)kDirHalf, cy = (float)b / (float)kDirHalf, cz = 1.f - fabsf(cx) - fabsf(cy);
+  if (cz < 0.f) {
+    const float fx = (1.f - fabsf(cy)) * (cx >= 0.f ? 1.f : -1.f), fy = (1.f - fabsf(cx)) * (cy >= 0.f ? 1.f : -1.f);
+    cx = fx; cy = fy;
+  }
+  const float cl = 1.f / sqrtf(cx * cx + cy * cy + cz * cz);
+  const float c[3] = {cx * cl, cy * cl, cz * cl};
+  int ax = 0;
+  if (fabsf(c[1]) < fabsf(c[ax])) ax = 1;
+  if (fabsf(c[2]) < fabsf(c[ax])) ax = 2;
+  float t1[3] = {-c[ax] * c[0], -c[ax] * c[1], -c[ax] * c[2]};
+  t1[ax] += 1.f;
+  const float tl = 1.f / sqrtf(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+  t1[0] *= tl; t1[1] *= tl; t1[2] *= tl;
+  const float t2[3] = {c[1] * t1[2] - c[2] * t1[1], c[2] * t1[0] - c[0] * t1[2], c[0] * t1[1] - c[1] * t1[0]};
+  // the point of the line closest to the box centre, in that frame; scale 1 / (2 E), E = the largest box extent
+  const float w[3] = {p[0] - 0.5f * V.bx, p[1] - 0.5f * V.by, p[2] - 0.5f * V.bz};
+  const float wd = w[0] * d[0] + w[1] * d[1] + w[2] * d[2];
+  const float q[3] = {w[0] - wd * d[0], w[1] - wd * d[1], w[2] - wd * d[2]};
+  const float ext = fmaxf(V.bx, fmaxf(V.by, V.bz));
+  const float sc = ext > 0.f ? 0.5f / ext : 0.f;
+  const float u = (q[0] * t1[0] + q[1] * t1[1] + q[2] * t1[2]) * sc + 0.5f;
+  const float v = (q[0] * t2[0] + q[1] * t2[1] + q[2] * t2[2]) * sc + 0.5f;
+  const float cells = (float)(1 << kPosBits);
+  const uint32_t qu = (uint32_t)fminf(fmaxf(u * cells, 0.f), cells - 1.f);
+  const uint32_t qv = (uint32_t)fminf(fmaxf(v * cells, 0.f), cells - 1.f);
+  const uint64_t cell = (uint64_t)((a + kDirHalf) * (2 * kDirHalf + 1) + (b + kDirHalf));
+  keys[i] = (cell << (2 * kPosBits)) | (uint64_t)hilbert2(qu, qv);
+}
+
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 static size_t radix_temp_bytes(size_t n) {
@@ -101,7 +183,7 @@ size_t sort_workspace_bytes(size_t n) {
 
 hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void* pos, const void* vel, int io_half,
                                     float dir_sign, void* ws, size_t ws_bytes, const uint32_t** perm_out,
-                                    hipStream_t stream) {
+                                    hipStream_t stream, bool chord_key) {
   (void)h;
   char* base = (char*)ws;
   const size_t k8 = al(n * sizeof(uint64_t)), k4 = al(n * sizeof(uint32_t));
@@ -111,12 +193,16 @@ hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void*
   uint32_t* idx_out = (uint32_t*)(base + 2 * k8 + k4);
   void* temp = base + 2 * k8 + 2 * k4;
   size_t temp_bytes = ws_bytes - (2 * k8 + 2 * k4);
-  hipLaunchKernelGGL(k_chord_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, V, n, pos, vel,
-                     io_half, dir_sign, keys_in, idx_in);
+  if (chord_key)
+    hipLaunchKernelGGL(k_chord_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, V, n, pos, vel,
+                       io_half, dir_sign, keys_in, idx_in);
+  else
+    hipLaunchKernelGGL(k_lightfield_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, V, n, pos, vel,
+                       io_half, dir_sign, keys_in, idx_in);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint64_t*)keys_in, keys_out,
-                                (const uint32_t*)idx_in, idx_out, n, 0u, (unsigned)kKeyBits, stream);
+                                (const uint32_t*)idx_in, idx_out, n, 0u, (unsigned)(chord_key ? kKeyBits : kLfKeyBits), stream);
   *perm_out = idx_out;
   return e;
 }

@@ -13,7 +13,7 @@ on CPU with gloo; the default is the HIP path (``drrt.TracerC``).
 from __future__ import annotations
 
 import os
-from typing import Callable, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple, Union
 
 import torch
 import torch.distributed as dist
@@ -44,11 +44,51 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def shard_rays(rank: int, world: int, *tensors: torch.Tensor):
-    """Slice every (N, ...) tensor to this rank's contiguous shard."""
+def shard_views(rays_per_view: Sequence[int], rank: int, world: int) -> List[Tuple[int, int]]:
+    """Global [lo, hi) of this rank's share of EVERY view of a multi-view ray set (``rays_per_view`` = the ``nrays`` list
+    the generators return, e.g. ``rand_rays_cube``): each view is split into `world` contiguous near-equal shards, so a
+    rank marches a strip of every view.  Views differ in cost (rays of an oblique view run up to 1.5x longer per
+    ray-step than those of an axis-aligned one), so a contiguous split of the concatenated set --
+    whole views to single ranks -- is unbalanced by construction; this one is balanced whatever the views are."""
+    out, base = [], 0
+    for n in rays_per_view:
+        lo, hi = shard_bounds(int(n), rank, world)
+        out.append((base + lo, base + hi))
+        base += int(n)
+    return out
+
+
+def shard_rays(rank: int, world: int, *tensors: torch.Tensor, views: Union[None, int, Sequence[int]] = None):
+    """Slice every (N, ...) tensor to this rank's shard.
+
+    views=None          one contiguous near-equal shard of the whole set (single-view sets);
+    views=k (int)       the set is k equal views back to back: a strip of every view, concatenated in view order;
+    views=[n0, n1, ..]  the same for views of different sizes (the generators' ``nrays`` list).
+    With views the rank's own per-view counts are ``[hi - lo for lo, hi in shard_views(...)]`` (``local_views``)."""
     n = tensors[0].shape[0]
-    lo, hi = shard_bounds(n, rank, world)
-    return tuple(t[lo:hi] for t in tensors)
+    if views is None:
+        lo, hi = shard_bounds(n, rank, world)
+        return tuple(t[lo:hi] for t in tensors)
+    per = _per_view(n, views)
+    spans = shard_views(per, rank, world)
+    return tuple(torch.cat([t[lo:hi] for lo, hi in spans]) for t in tensors)
+
+
+def _per_view(n: int, views: Union[int, Sequence[int]]) -> List[int]:
+    if isinstance(views, int):
+        if views < 1 or n % views:
+            raise ValueError(f"{n} rays do not split into {views} equal views; pass the per-view counts")
+        return [n // views] * views
+    per = [int(v) for v in views]
+    if sum(per) != n:
+        raise ValueError(f"per-view counts sum to {sum(per)}, the set has {n} rays")
+    return per
+
+
+def local_views(n: int, views: Union[int, Sequence[int]], rank: int, world: int) -> List[int]:
+    """This rank's ray count per view after ``shard_rays(..., views=views)`` -- what a per-view sensor loop splits by
+    (``xmp.split(rpv)``, core/image_opt.py:102)."""
+    return [hi - lo for lo, hi in shard_views(_per_view(n, views), rank, world)]
 
 
 def allreduce_grad(grad: torch.Tensor, group=None) -> torch.Tensor:
@@ -56,6 +96,32 @@ def allreduce_grad(grad: torch.Tensor, group=None) -> torch.Tensor:
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
     return grad
+
+
+class _AllReduceImage(torch.autograd.Function):
+    """forward: all-reduce(sum) of the per-rank partial images; backward: identity.  Every rank goes on to evaluate
+    the SAME loss on the SAME summed image, so dL/d(total) is already identical everywhere and
+    d(total)/d(partial of this rank) = I: no collective in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, img, group):
+        out = img.detach().clone()
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def allreduce_image(img: torch.Tensor, group=None) -> torch.Tensor:
+    """Differentiable all-reduce(sum) of a sensor image for image losses on ray shards: the reference
+    normalises and compares WHOLE images (``sum_norm`` + MSE, core/image_opt.py:99-112), which are sums over rays, so
+    each rank splats its own rays (``sensor.generate_sensor``), the partial images (512^2 x 4 B = 1 MiB) are summed
+    here BEFORE the normalisation, every rank computes the same loss, and each rank back-propagates through its own
+    rays only; ``ShardedBackTracerC.backward`` then sums the per-rank dL/dn grids.  One rank: the identity."""
+    return _AllReduceImage.apply(img, group)
 
 
 def _hip_trace(rif_flat, shape, x, v, h, ds):

@@ -85,6 +85,9 @@ extern "C" {
 #define DRRT_FLAG_Q16_POS_ONLY 0x200000u  /* drrt_trace_q16io / drrt_backtrace_q16io: only the POSITION arrays are q16 codes;
                                              directions and adjoint seeds are fp32 arrays (18 B per exit ray instead of 12) */
 #define DRRT_FLAG_LEGACY_FORWARD 0x100000u /* trace, trace_pln, trace_target (A-B measurement; bit-identical results): k_trace<MODE> / k_target_a instead of the flat kernels */
+#define DRRT_FLAG_CHORD_KEY 0x800000u      /* with SORT_RAYS (A-B measurement; same results): the rounds-1/2 sort key (6-D Morton interleave of the
+                                              chord end points) instead of the light-field key (direction cell + Hilbert index of the
+                                              transverse offset, csrc/drrt_sort.hip) */
 #define DRRT_FLAG_STATIC_WINDOW 0x400000u  /* backtrace (A-B measurement; same results up to fp32 summation order): always the
                                              kernel with compile-time 9^3 gradient windows, no per-call bundle classification */
 #define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace, backtrace_sdf (A-B measurement; same results up to fp32 summation order): the round-1
