@@ -32,6 +32,7 @@ FLAG_LEGACY_FORWARD = 0x100000
 FLAG_Q16_POS_ONLY = 0x200000
 FLAG_STATIC_WINDOW = 0x400000
 FLAG_CHORD_KEY = 0x800000
+FLAG_RING_WINDOW = 0x1000000
 ADAM_MASK_BOUNDARY, ADAM_CLAMP_MIN = 1, 2
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
@@ -92,6 +93,8 @@ SIGNATURES = {
     "drrt_last_order": (_vp, [_vp]),
     "drrt_set_order_hint": (None, [_vp, _sz]),
     "drrt_order_hint_pending": (_sz, []),
+    "drrt_last_steps": (_vp, [_vp]),
+    "drrt_set_step_hint": (None, [_vp, _sz]),
     "drrt_profile_begin": (_i, [_i]),
     "drrt_profile_collect": (_i, [_vp, _vp, _i]),
     "drrt_profile_end": (None, []),

@@ -16,7 +16,10 @@ All methods ``detach()`` / ``contiguous()`` / cast to fp32 exactly where the ref
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import dataclasses
+import threading
 from dataclasses import dataclass
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -33,6 +36,9 @@ class Options:
                                   # sync per call; the message may appear one call late -- see flush_warnings())
     direct_atomics: bool = False  # adjoint: one global atomic per tap (debug / A-B)
     legacy_adjoint: bool = False  # adjoint: the round-1 window kernel instead of k_backtrace_flat (DRRT_FLAG_LEGACY_ADJOINT, A-B)
+    adjoint_window: str = "auto"  # adjoint: "auto" = the bundles of the call are classified on the device and the box-window kernel
+                                  # (k_backtrace_flat) or the ring-window kernel (k_backtrace_ring) runs; "box" / "ring" force one
+    chord_key: bool = False       # locality sort with the rounds-1/2 key (DRRT_FLAG_CHORD_KEY, A-B)
     lds_bricks: bool = False      # forward: opt-in LDS-staged bricks of the grid (bit-identical; slower on MI355X)
     pair_grid: object = "auto"    # the "pair copy" of the grid in the workspace (DRRT_FLAG_PAIR_GRID; 8 bytes per voxel, two
                                   # 16-byte gathers per cell instead of four 8-byte ones).  True, False, or "auto" = a
@@ -50,7 +56,28 @@ class Options:
         self.pair_grid = v
 
 
-options = Options()
+options = Options()          # the process-wide defaults
+
+# Per-thread overrides: `with drrt.using(sort_rays=False): ...` changes the options of the calls made by THIS thread inside
+# the block and nothing else (two threads with different settings do not race on the module global; the visit-order hint
+# of the C ABI is per thread in the same way).  Calls outside any block read the module-level `options`.
+_tls = threading.local()
+
+
+def _opt() -> Options:
+    return getattr(_tls, "options", None) or options
+
+
+@contextlib.contextmanager
+def using(**overrides):
+    """Context manager: the tracer calls of the current thread run with `overrides` applied on top of the options in
+    effect (``with drrt.using(corrected_h=True, pair_grid=False): ...``); restored on exit, nestable."""
+    prev = getattr(_tls, "options", None)
+    _tls.options = dataclasses.replace(prev or options, **overrides)
+    try:
+        yield _tls.options
+    finally:
+        _tls.options = prev
 
 # last call's statistics (ray_steps, n_failed, iters) as a device tensor of 3 int64 words
 last_stats: Optional[torch.Tensor] = None
@@ -71,15 +98,21 @@ def _wkey(device: torch.device) -> tuple:
 
 def _flags(adjoint: bool = False) -> int:
     f = 0
-    if options.sort_rays:
+    if _opt().sort_rays:
         f |= _lib.FLAG_SORT_RAYS
-    if adjoint and options.corrected_h:
+    if adjoint and _opt().corrected_h:
         f |= _lib.FLAG_CORRECTED_H
-    if adjoint and options.direct_atomics:
+    if adjoint and _opt().direct_atomics:
         f |= _lib.FLAG_DIRECT_ATOMICS
-    if adjoint and options.legacy_adjoint:
+    if adjoint and _opt().legacy_adjoint:
         f |= _lib.FLAG_LEGACY_ADJOINT
-    if not adjoint and options.lds_bricks:
+    if adjoint and _opt().adjoint_window == "box":
+        f |= _lib.FLAG_STATIC_WINDOW
+    if adjoint and _opt().adjoint_window == "ring":
+        f |= _lib.FLAG_RING_WINDOW
+    if _opt().chord_key:
+        f |= _lib.FLAG_CHORD_KEY
+    if not adjoint and _opt().lds_bricks:
         f |= _lib.FLAG_LDS_BRICKS
     if adjoint and _EXPERIMENT:
         f |= (_EXPERIMENT & 0xFF) << 8          # development ablations of the adjoint kernel (include/drrt_hip.h)
@@ -116,7 +149,7 @@ def _march_workspace(rif_: torch.Tensor, res, n: int, h: float, ds: float, flags
     copy built from this very tensor (same storage, same version counter, same layout) and no other call has
     used the workspace since.  With "auto" an adjoint never builds the copy itself (it gains ~2 %, less than the
     copy costs): it uses it only when it can reuse the forward's."""
-    q = options.pair_grid
+    q = _opt().pair_grid
     auto = q == "auto"
     if auto:
         # the copy moves 12 B per voxel; the gathers it halves only bound the march when the GPU is full of waves
@@ -230,7 +263,7 @@ def _capture_order(n: int, device: torch.device) -> None:
     """Copy the permutation the library just left in the workspace (device-to-device, async)."""
     global last_order
     last_order = None
-    if not options.sort_rays or n < 2:
+    if not _opt().sort_rays or n < 2:
         return
     cnt = C.c_size_t(0)
     ptr = _lib.load().drrt_last_order(C.byref(cnt))
@@ -240,17 +273,28 @@ def _capture_order(n: int, device: torch.device) -> None:
     off = int(ptr) - ws.data_ptr()
     if 0 <= off and off + 4 * n <= ws.numel():
         last_order = ws[off:off + 4 * n].view(torch.int32).clone()
+        # the forward march's per-ray iteration counts ride along ON the order tensor (attribute `drrt_steps`), so every
+        # holder of the order -- tracer.Back*TracerC's ctx, dist.ShardedBackTracerC -- hands both to the paired adjoint:
+        # its rays then start on the forward march's clock (step hint, include/drrt_hip.h)
+        ptr_s = _lib.load().drrt_last_steps(C.byref(cnt))
+        off_s = int(ptr_s) - ws.data_ptr() if ptr_s else -1
+        if ptr_s and cnt.value == n and 0 <= off_s and off_s + 4 * n <= ws.numel():
+            last_order.drrt_steps = ws[off_s:off_s + 4 * n].view(torch.int32).clone()
 
 
 def _hint(order: Optional[torch.Tensor], n: int) -> None:
     if order is not None and order.numel() == n and order.dtype == torch.int32 and order.is_cuda:
         _lib.load().drrt_set_order_hint(C.c_void_p(order.data_ptr()), n)
+        steps = getattr(order, "drrt_steps", None)
+        if steps is not None and steps.numel() == n and steps.dtype == torch.int32 and steps.device == order.device:
+            _lib.load().drrt_set_step_hint(C.c_void_p(steps.data_ptr()), n)
 
 
 def _clear_hint() -> None:
     """The library consumes a hint at the entry of the next march call; this covers the paths on which that call
     is never reached (an exception while marshalling arguments)."""
     _lib.load().drrt_set_order_hint(None, 0)
+    _lib.load().drrt_set_step_hint(None, 0)
 
 
 # "failed to exit all rays" (src/tracer.cpp:90) without a host sync per call: the stats block is copied to pinned
@@ -260,7 +304,18 @@ _pending_warn: list = []      # (event, pinned host tensor)
 _pinned_pool: list = []
 
 
+def _capturing() -> bool:
+    """True while the current stream is being captured into a HIP graph: event queries, pinned allocations and host
+    copies are not capturable, so the failed-ray bookkeeping stands still during a capture."""
+    try:
+        return torch.cuda.is_current_stream_capturing()
+    except Exception:
+        return False
+
+
 def _drain_warnings(block: bool = False) -> None:
+    if _capturing():
+        return
     while _pending_warn and (block or _pending_warn[0][0].query()):
         ev, host = _pending_warn.pop(0)
         if block:
@@ -289,7 +344,7 @@ _atexit.register(_at_exit)
 
 def _warn_failed(stats: torch.Tensor) -> None:
     _drain_warnings()
-    if not options.check_failed:
+    if not _opt().check_failed or _capturing():      # a captured march reports through its stats block only
         return
     host = _pinned_pool.pop() if _pinned_pool else torch.empty(3, dtype=torch.int64, pin_memory=True)
     host.copy_(stats, non_blocking=True)

@@ -86,6 +86,12 @@ class MaskedAdam(optim.Optimizer):
                         float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]),
                         float(group["clamp_min"] if group["clamp_min"] is not None else 0.0), flags,
                         C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)))
+                # The kernel wrote p and p.grad through raw pointers: tell autograd, as any in-place torch op would.  The
+                # version counters are what tracer.Back*TracerC's save_for_backward check and the pair-copy reuse token
+                # of drrt._march_workspace key on -- without the bump a retained-graph backward after step() would
+                # silently pair the NEW grid with the stale pair copy of the old one.
+                torch.autograd.graph.increment_version(p)
+                torch.autograd.graph.increment_version(g)
         return loss
 
 

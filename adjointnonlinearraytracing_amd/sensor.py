@@ -92,6 +92,16 @@ def _vec3(t: torch.Tensor):
     return (C.c_float * 3)(*v)
 
 
+def _single_plane(*vecs) -> None:
+    """The fused sensor operators take ONE plane / frame per call (the reference calls them once per view with (1, 3)
+    tensors, core/image_opt.py:99-119).  A (N, 3) tensor whose rows differ -- per-ray planes -- would silently use row 0:
+    refuse it (``trace_rays_to_plane`` is the operator that takes per-ray planes)."""
+    for t in vecs:
+        if isinstance(t, torch.Tensor) and t.dim() == 2 and t.shape[0] > 1 and not bool((t == t[:1]).all()):
+            raise RuntimeError("this sensor operator takes one plane / frame per call (rows differ); split the rays by "
+                               "view as the reference does (core/image_opt.py:99-119)")
+
+
 def _frame(dev, p, n, t1, t2):
     """The sensor frame of a call -> (frame12, host): when every given vector is a tensor on `dev` (the reference keeps
     its planes there, core/image_opt.py:88-119) they are packed into ONE 12-float device tensor (p, n, t1, t2; zeros for
@@ -229,6 +239,12 @@ class _TexGet(torch.autograd.Function):
     def forward(ctx, x, v, tex, p, n, t1, t2, span, mode):
         if not x.is_cuda:
             raise RuntimeError("get_sdf_vals_* expect tensors on the cuda (ROCm) device (no CPU path)")
+        if isinstance(tex, torch.Tensor) and tex.requires_grad:
+            # the reference's Grid.Get path is differentiable w.r.t. the texture; this fused operator only returns the
+            # gradients of the rays -- say so instead of handing back a silent zero
+            raise RuntimeError("get_sdf_vals_*: the fused operator is not differentiable w.r.t. the texture; pass "
+                               "d_tex.detach() (the experiments optimise the volume, not the measured texture)")
+        _single_plane(p, n, t1, t2)
         dev = x.device
         with torch.cuda.device(dev):
             x_ = x.detach().to(torch.float32).contiguous()

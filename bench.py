@@ -73,6 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--direct-atomics", action="store_true")
     ap.add_argument("--lds-bricks", action="store_true", help="forward: opt-in LDS-staged grid bricks")
+    ap.add_argument("--no-step-hint", action="store_true", help="adjoint rays start at their own exit sample (A-B)")
     ap.add_argument("--no-order-reuse", action="store_true",
                     help="adjoint computes its own visit order instead of reusing the forward's")
     ap.add_argument("--pair", choices=["auto", "on", "off"], default="auto",
@@ -92,6 +93,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the `variants` leg (the reference's six rotated views and the shifted plane source)")
     ap.add_argument("--variant-steps", type=int, default=5)
+    ap.add_argument("--variants", default="cube6_rotated,plane_shifted", help="comma list of the variants to run")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
                                                         "to rehearse the multi-rank flow on a 1-GPU box)")
     args = ap.parse_args(argv)
@@ -442,6 +444,8 @@ def run_rank(args) -> int:
                                           p(st_f), p(ws), ws.numel(), fflags, stream))
             if (flags & _lib.FLAG_SORT_RAYS) and not args.no_order_reuse:    # adjoint visits rays in the forward's bundle order
                 lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
+                if not args.no_step_hint:                                    # ... on the forward march's clock
+                    lib.drrt_set_step_hint(lib.drrt_last_steps(None), n)
             _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),
                                               p(st_a), p(ws), ws.numel(), aflags, stream))
             if use_dist:
@@ -470,8 +474,12 @@ def run_rank(args) -> int:
             dbg = ws[off:off + 512].view(torch.int64).cpu().tolist()
             print(f"[debug] window flushes {dbg[0]}, ray-steps via LDS window {dbg[1]}, via global fallback {dbg[2]}, "
                   f"fitted waves {dbg[3]}; leaves: one face -> window {dbg[4]} (lanes adding after pre-reduction {dbg[5]}), "
-                  f"one face -> global {dbg[6]}, all eight {dbg[7]}; wave-steps {dbg[8]}, with >= 2 axes leaving {dbg[9]}",
-                  file=sys.stderr)
+                  f"one face -> global {dbg[6]}, all eight {dbg[7]}; wave-steps {dbg[8]}, with >= 2 axes leaving {dbg[9]}; "
+                  f"ring kernel: [0..2] = full flushes / slides / fits; no window for the box {dbg[10]}, services {dbg[11]}, "
+                  f"lanes left outside {dbg[12]}, fitted volume sum {dbg[13]}, all eight -> global {dbg[14]}, "
+                  f"ray-steps in clamped cells {dbg[15]}; sample of boxes without a window (step, ex, ey, ez, lanes, block): "
+                  + str([(dbg[17 + 4 * k], dbg[18 + 4 * k] & 0xffff, (dbg[18 + 4 * k] >> 16) & 0xffff, dbg[18 + 4 * k] >> 32,
+                          dbg[19 + 4 * k], dbg[20 + 4 * k]) for k in range(11)]), file=sys.stderr)
         fwd_steps = int(st_f[0].item()); adj_steps = int(st_a[0].item())
         n_failed = int(st_f[1].item())
         t = torch.tensor([elapsed, float(fwd_steps), float(adj_steps)], dtype=torch.float64, device=dev)
@@ -623,7 +631,7 @@ def run_rank(args) -> int:
             base_ns = ms_adj * 1e6 / max(adj_steps, 1)
             out["variants"] = {"headline_adj_ns_per_ray_step": base_ns,
                                "headline_fwd_ns_per_ray_step": ms_fwd * 1e6 / max(fwd_steps, 1)}
-            for name in ("cube6_rotated", "plane_shifted"):
+            for name in [v for v in args.variants.split(",") if v]:
                 v = run_variant(name)
                 v["adj_ns_ratio_to_headline"] = v["adj_ns_per_ray_step"] / base_ns
                 out["variants"][name] = v

@@ -2,7 +2,7 @@
 """The reference's fibre experiment (core/fiber_opt.py:100-280) on this package's mirrors: optimise the RADIAL index profile
 of a cylindrical fibre so that light entering through a cone (or as a plane wave) refocuses on the axis point it left
 from, one "hop" further down, and again a hop later -- `tracer.BackCableTracerC` (HIP cable march + adjoint),
-`cable.Cable.GetLinear` for the boundary index, `source.cone_source3_rand` / `plane_source3_rand`, Adam with the
+a three-line radial lookup for the boundary index (the reference: `cable.Cable.GetLinear`, core/fiber_opt.py:158-160), `source.cone_source3_rand` / `plane_source3_rand`, Adam with the
 experiment's own midpoint up-sampling between levels.
 
     python examples/fiber_demo.py [--res 5 9 17] [--iters 30] [--nbins 32] [--src cone|planar]
@@ -18,7 +18,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.optim as optim
 
-from adjointnonlinearraytracing_amd import cable, drrt, source, tracer
+from adjointnonlinearraytracing_amd import drrt, source, tracer
+
+
+def radial_index(profile: torch.Tensor, radius: float, pts: torch.Tensor) -> torch.Tensor:
+    """n at the points' distance from the fibre axis (x = z = radius): the profile's samples lie h = radius / (len - 1)
+    apart, linear in between, constant beyond the last one.  Differentiable w.r.t. the profile."""
+    r = torch.hypot(pts[:, 0] - radius, pts[:, 2] - radius) * ((profile.shape[0] - 1) / radius)
+    lo = r.floor().long().clamp(0, profile.shape[0] - 1)
+    hi = (lo + 1).clamp(max=profile.shape[0] - 1)
+    return torch.lerp(profile[lo], profile[hi], (r - lo).clamp(0, 1))
 
 
 def upres_scene(n: torch.Tensor) -> torch.Tensor:
@@ -46,8 +55,7 @@ def run(res_list=(5, 9, 17), iters=30, nbins=32, spp=1, src_type="cone", cable_l
     def trace(nt, rays, target):                                          # :152-163
         x, v = rays
         sds = cable_radius / nt.shape[0] / 2
-        n_bound, _ = cable.Cable(nt, cable_radius, cable_length).GetLinear(x)
-        v = v / n_bound[:, None]
+        v = v / radial_index(nt, cable_radius, x)[:, None]
         return tracer.BackCableTracerC.apply(nt, cable_radius, cable_length, x, v, target, sds)
 
     n = torch.ones(res_list[0], device=dev).requires_grad_(True)

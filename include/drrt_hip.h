@@ -88,6 +88,8 @@ extern "C" {
 #define DRRT_FLAG_CHORD_KEY 0x800000u      /* with SORT_RAYS (A-B measurement; same results): the rounds-1/2 sort key (6-D Morton interleave of the
                                               chord end points) instead of the light-field key (direction cell + Hilbert index of the
                                               transverse offset, csrc/drrt_sort.hip) */
+#define DRRT_FLAG_RING_WINDOW 0x1000000u   /* backtrace, backtrace_sdf: the ring-window adjoint kernel (k_backtrace_ring: the wave's LDS window is
+                                              addressed modulo its size and follows the rays; each voxel is flushed once) */
 #define DRRT_FLAG_STATIC_WINDOW 0x400000u  /* backtrace (A-B measurement; same results up to fp32 summation order): always the
                                              kernel with compile-time 9^3 gradient windows, no per-call bundle classification */
 #define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace, backtrace_sdf (A-B measurement; same results up to fp32 summation order): the round-1
@@ -159,6 +161,17 @@ DRRT_API void drrt_set_order_hint(const uint32_t* order, size_t n);
 /* Length of the hint currently armed on this host thread (0 = none): lets a binding assert that no hint
  * survives a call. */
 DRRT_API size_t drrt_order_hint_pending(void);
+/* ---- step hint (optimisation hint of the same kind; results do not depend on it) ---------------------------------
+ * A forward march (drrt_trace_f32 / _f16io / _q16io / drrt_trace_pln_f32 called with a workspace) leaves the number of
+ * march iterations of every ray -- n uint32, caller ray order -- in the workspace; drrt_last_steps() returns that
+ * device pointer (valid until the workspace is overwritten; NULL when the last forward call on this thread wrote none).
+ * drrt_set_step_hint(steps, n) hands them to the NEXT drrt_backtrace_* call on this host thread (consumed at its entry,
+ * like the order hint; ignored when n differs): the rays of a wave then start the adjoint on the forward march's clock
+ * (a ray that left d iterations before the last one of its wave starts d iterations later, d <= 96), so a bundle that
+ * was compact in the forward march is compact in the adjoint too, whatever the exit face.  Only WHEN a lane does its
+ * k-th step changes; every ray still gets its max_steps iterations (src/tracer.cpp:417).  Wrong counts cost speed only. */
+DRRT_API const uint32_t* drrt_last_steps(size_t* n_out);
+DRRT_API void drrt_set_step_hint(const uint32_t* steps, size_t n);
 
 /* ---- 16-bit ray state "q16" (BASELINE.json config 5: "fp16 ray state + fp32 adjoint accumulate") -----------------
  * The reference is fp32-only (include/types.h:36-46).  IEEE half keeps 11 significant bits wherever the value is:

@@ -93,3 +93,127 @@ def test_world2_gloo_allreduce_gives_global_gradient(tmp_path, oracle):
     assert cases.rel_l2(g0.ravel(), b["grad"]) < 1e-5        # shard sum == global, up to fp32 reassociation
     l0 = float(np.load(tmp_path / "loss_0.npy"))
     assert abs(l0 - float((o["xt"].astype(np.float64) ** 2).sum() + o["vt"].astype(np.float64).sum())) < 1e-2
+
+
+# ---- image losses on ray shards (core/image_opt.py:99-112) --------------------------------------------------
+class _CpuSensor(torch.autograd.Function):
+    """Test stand-in for sensor.generate_sensor (HIP): oracle/sensor_ref.py's numpy splat + analytic backward."""
+
+    @staticmethod
+    def forward(ctx, x, v, p, n, res, span):
+        from oracle import sensor_ref as SR
+        ctx.args = (x.detach().numpy(), v.detach().numpy(), p.numpy(), n.numpy(), res, span)
+        return torch.from_numpy(SR.generate_sensor(ctx.args[0], ctx.args[1], 1.0, ctx.args[2], ctx.args[3], res, span))
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import sensor_ref as SR
+        x, v, p, n, res, span = ctx.args
+        gx, gv = SR.generate_sensor_backward(x, v, 1.0, p, n, res, span, g.numpy())
+        return torch.from_numpy(gx), torch.from_numpy(gv), None, None, None, None
+
+
+_IMG = dict(R=17, span=1.0, res=12, views=2, per_view=150)
+
+
+def _image_problem():
+    """Two plane views (+y and +x), a fixed target image per view."""
+    import cases
+    R, span = _IMG["R"], _IMG["span"]
+    h = span / (R - 1); ds = h / 2
+    rif = cases.smooth_field(R, seed=7, amp=0.05)
+    xs, vs, planes = [], [], []
+    for k, axis in enumerate((1, 0)):
+        p, v = cases.plane_rays(_IMG["per_view"], span, ds, seed=11 + k, axis=axis, tilt=0.02, lo=0.25, hi=0.75)
+        xs.append(p); vs.append(v)
+        nrm = np.zeros(3); nrm[axis] = 1.0
+        planes.append((np.full(3, span / 2) + nrm * span * 0.6, nrm))
+    rng = np.random.default_rng(3)
+    targets = [rng.uniform(0.5, 1.5, (_IMG["res"], _IMG["res"])) for _ in planes]
+    return rif, np.concatenate(xs).astype(np.float32), np.concatenate(vs).astype(np.float32), planes, targets, h, ds
+
+
+def _image_loss(xt, vt, counts, planes, targets, reduce_fn):
+    """core/image_opt.py:99-112 in small: per view, splat the view's rays into its sensor image, sum over ranks
+    (`reduce_fn`), normalise to unit mean (source.sum_norm), MSE against the measurement; mean over views."""
+    loss = 0.0
+    for xv, vv, (p, n), tgt in zip(xt.split(counts), vt.split(counts), planes, targets):
+        img = _CpuSensor.apply(xv.double(), vv.double(), torch.from_numpy(p), torch.from_numpy(n), _IMG["res"], _IMG["span"])
+        img = reduce_fn(img)
+        img = img * (img.numel() / img.sum())
+        loss = loss + torch.mean((img - torch.from_numpy(tgt)) ** 2)
+    return loss / len(planes)
+
+
+def _image_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from adjointnonlinearraytracing_amd import dist as D
+    D.init_from_env(backend="gloo")
+    rif_np, pos, vel, planes, targets, h, ds = _image_problem()
+    rif = torch.from_numpy(rif_np).requires_grad_(True)
+    pos, vel = torch.from_numpy(pos), torch.from_numpy(vel)
+    n, views = pos.shape[0], _IMG["views"]
+    x, v = D.shard_rays(rank, world, pos, vel, views=views)               # a strip of EVERY view on every rank
+    counts = D.local_views(n, views, rank, world)
+    assert sum(counts) == x.shape[0] and min(counts) > 0
+    xt, vt = D.ShardedBackTracerC.apply(rif, x, v, h, ds, None, _oracle_trace, _oracle_backtrace)
+    loss = _image_loss(xt, vt, counts, planes, targets, D.allreduce_image)
+    loss.backward()
+    np.save(os.path.join(out_dir, f"igrad_{rank}.npy"), rif.grad.numpy())
+    np.save(os.path.join(out_dir, f"iloss_{rank}.npy"), np.asarray(float(loss)))
+    np.save(os.path.join(out_dir, f"icounts_{rank}.npy"), np.asarray(counts))
+    dist.destroy_process_group()
+
+
+def test_shard_rays_interleaves_views():
+    from adjointnonlinearraytracing_amd import dist as D
+    x = torch.arange(26)
+    per = [10, 9, 7]
+    got = [D.shard_rays(r, 3, x, views=per)[0].tolist() for r in range(3)]
+    assert sorted(sum(got, [])) == list(range(26))                         # a partition of the set
+    bounds = np.cumsum([0] + per)
+    for r in range(3):
+        lv = D.local_views(26, per, r, 3)
+        assert all(c > 0 for c in lv) and sum(lv) == len(got[r])          # every rank holds rays of every view
+        k = 0
+        for vi, c in enumerate(lv):                                       # ... in view order, contiguous strips
+            assert all(bounds[vi] <= e < bounds[vi + 1] for e in got[r][k:k + c]); k += c
+    assert D.shard_rays(1, 2, torch.arange(12), views=3)[0].tolist() == [2, 3, 6, 7, 10, 11]
+    with pytest.raises(ValueError):
+        D.shard_rays(0, 2, torch.arange(10), views=3)
+
+
+@pytest.mark.timeout(300)
+def test_world2_image_loss_on_ray_shards(tmp_path, oracle):
+    """An image-MSE loss through per-view sensor images on ray shards: with dist.allreduce_image (forward all-reduce,
+    backward identity) and dist.ShardedBackTracerC every rank gets the loss and the dL/dn of the single-process run."""
+    world, port = 2, 29811 + (os.getpid() % 150)
+    mp.spawn(_image_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = np.load(tmp_path / "igrad_0.npy"), np.load(tmp_path / "igrad_1.npy")
+    assert np.array_equal(g0, g1)
+    assert float(np.load(tmp_path / "iloss_0.npy")) == pytest.approx(float(np.load(tmp_path / "iloss_1.npy")), rel=1e-12)
+    # single process, all rays
+    rif_np, pos, vel, planes, targets, h, ds = _image_problem()
+    rif = torch.from_numpy(rif_np).requires_grad_(True)
+
+    class _Single(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, r, x, v):
+            o = _oracle_trace(r.detach().flatten(), r.shape, x, v, h, ds)
+            ctx.save_for_backward(r, o[0], o[1]); ctx.order = o[2]
+            return o[0], o[1]
+
+        @staticmethod
+        def backward(ctx, gx, gv):
+            r, xt, vt = ctx.saved_tensors
+            return _oracle_backtrace(r.detach().flatten(), r.shape, xt, vt, gx, gv, h, ds, order=ctx.order).reshape(r.shape), None, None
+
+    xt, vt = _Single.apply(rif, torch.from_numpy(pos), torch.from_numpy(vel))
+    counts = [_IMG["per_view"]] * _IMG["views"]
+    loss = _image_loss(xt, vt, counts, planes, targets, lambda im: im)
+    loss.backward()
+    import cases
+    assert float(np.load(tmp_path / "iloss_0.npy")) == pytest.approx(float(loss), rel=1e-9)
+    assert cases.rel_l2(g0, rif.grad.numpy()) < 1e-5
+    assert float(np.abs(g0).sum()) > 0

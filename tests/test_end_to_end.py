@@ -67,7 +67,7 @@ def test_image_experiment_flow(gpu, sdf_weight):
 @pytest.mark.parametrize("src", ["cone", "planar"])
 def test_fibre_experiment_flow(gpu, src):
     """examples/fiber_demo.py: the flow of core/fiber_opt.py -- cone / plane source, boundary index through
-    cable.Cable.GetLinear, tracer.BackCableTracerC towards two targets a hop apart, Adam on the radial profile with the
+    a radial index lookup, tracer.BackCableTracerC towards two targets a hop apart, Adam on the radial profile with the
     experiment's midpoint up-sampling: the refocusing loss must fall by a large factor."""
     import fiber_demo
     n, hist = fiber_demo.run(res_list=(5, 9), iters=20, nbins=24, src_type=src, verbose=False)
