@@ -7,11 +7,12 @@
 //
 // Round 3 key ("light-field key", the default): a ray is the line it travels on, i.e. a direction and a 2-D offset in the
 // plane perpendicular to it.
-//   direction  octahedral map of the unit direction, cut into 33 x 33 cells (an ODD count: +-x, +-y, +z are cell CENTRES);
+//   direction  octahedral map of the unit direction, cut into 31 x 31 cells (an ODD count: +-x, +-y, +z are cell CENTRES);
 //              the cell index is the major part of the key, so a collimated view is one contiguous key range;
 //   offset     the point of the line closest to the box centre, in the orthonormal frame (t1, t2) of the CELL's centre
 //              direction (every ray of a cell uses the same frame), scaled by a power of two of the box extent and cut
-//              into 2048 x 2048 cells; the minor part of the key is the HILBERT index of that cell.
+//              into 2048 x 2048 cells; the minor part of the key is the HILBERT index of that cell.  10 + 22 bits: a 32-bit
+//              key (the sort moves 8 instead of 12 bytes per ray and pass).
 // Why Hilbert and not the Z-order interleave of rounds 1-2: 64 consecutive rays of a Z-order are an aligned 8 x 8 tile only
 // when the sampling grid happens to be aligned with the key cells (the metric's pixel-aligned plane source); shift the
 // same source by a third of a pixel and 11 % of the bundles straddle two far-apart tiles (measured: adjoint 4.8 -> 7.1 ms),
@@ -90,9 +91,9 @@ __global__ void __launch_bounds__(256) k_chord_keys(Vol V, size_t n, const void*
 }
 
 // ---- light-field key ---------------------------------------------------------------------------------------------
-constexpr int kDirHalf = 16;                         // direction cells per octahedral axis: 2 * kDirHalf + 1 = 33
+constexpr int kDirHalf = 15;                         // direction cells per octahedral axis: 2 * kDirHalf + 1 = 31
 constexpr int kPosBits = 11;                         // offset cells per axis: 2048
-constexpr int kLfKeyBits = 2 * kPosBits + 11;        // 22 + 11 (33 * 33 = 1089 direction cells < 2^11)
+constexpr int kLfKeyBits = 2 * kPosBits + 10;        // 22 + 10 (31 * 31 = 961 direction cells < 2^10): 32 bits
 
 __device__ __forceinline__ uint32_t hilbert2(uint32_t x, uint32_t y) {      // x, y < 2^kPosBits
   uint32_t d = 0;
@@ -111,7 +112,7 @@ __device__ __forceinline__ uint32_t hilbert2(uint32_t x, uint32_t y) {      // x
 
 __global__ void __launch_bounds__(256) k_lightfield_keys(Vol V, size_t n, const void* __restrict__ pos,
                                                          const void* __restrict__ vel, int io_half, float dir_sign,
-                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float p[3] = {ldr(V, pos, 3 * i, io_half, true), ldr(V, pos, 3 * i + 1, io_half, true), ldr(V, pos, 3 * i + 2, io_half, true)};
@@ -159,18 +160,22 @@ __global__ void __launch_bounds__(256) k_lightfield_keys(Vol V, size_t n, const 
   const float cells = (float)(1 << kPosBits);
   const uint32_t qu = (uint32_t)fminf(fmaxf(u * cells, 0.f), cells - 1.f);
   const uint32_t qv = (uint32_t)fminf(fmaxf(v * cells, 0.f), cells - 1.f);
-  const uint64_t cell = (uint64_t)((a + kDirHalf) * (2 * kDirHalf + 1) + (b + kDirHalf));
-  keys[i] = (cell << (2 * kPosBits)) | (uint64_t)hilbert2(qu, qv);
+  const uint32_t cell = (uint32_t)((a + kDirHalf) * (2 * kDirHalf + 1) + (b + kDirHalf));
+  keys[i] = (cell << (2 * kPosBits)) | hilbert2(qu, qv);
 }
 
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 static size_t radix_temp_bytes(size_t n) {
-  size_t temp = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, temp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+  size_t t64 = 0, t32 = 0;          // both key widths share the buffers: the larger temporary storage
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, t64, (const uint64_t*)nullptr, (uint64_t*)nullptr,
                                           (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0u, (unsigned)kKeyBits,
                                           (hipStream_t)0);
-  if (e != hipSuccess || temp == 0) {   // no device visible (CPU-only import): conservative bound
+  hipError_t e2 = rocprim::radix_sort_pairs(nullptr, t32, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                           (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0u, (unsigned)kLfKeyBits,
+                                           (hipStream_t)0);
+  size_t temp = t64 > t32 ? t64 : t32;
+  if (e != hipSuccess || e2 != hipSuccess || temp == 0) {   // no device visible (CPU-only import): conservative bound
     (void)hipGetLastError();
     temp = n * 32 + (1u << 20);
   }
@@ -193,16 +198,22 @@ hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void*
   uint32_t* idx_out = (uint32_t*)(base + 2 * k8 + k4);
   void* temp = base + 2 * k8 + 2 * k4;
   size_t temp_bytes = ws_bytes - (2 * k8 + 2 * k4);
-  if (chord_key)
+  hipError_t e;
+  if (chord_key) {
     hipLaunchKernelGGL(k_chord_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, V, n, pos, vel,
                        io_half, dir_sign, keys_in, idx_in);
-  else
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint64_t*)keys_in, keys_out,
+                                  (const uint32_t*)idx_in, idx_out, n, 0u, (unsigned)kKeyBits, stream);
+  } else {                                     // 32-bit keys in the same buffers
     hipLaunchKernelGGL(k_lightfield_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, V, n, pos, vel,
-                       io_half, dir_sign, keys_in, idx_in);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint64_t*)keys_in, keys_out,
-                                (const uint32_t*)idx_in, idx_out, n, 0u, (unsigned)(chord_key ? kKeyBits : kLfKeyBits), stream);
+                       io_half, dir_sign, (uint32_t*)keys_in, idx_in);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)keys_out,
+                                  (const uint32_t*)idx_in, idx_out, n, 0u, (unsigned)kLfKeyBits, stream);
+  }
   *perm_out = idx_out;
   return e;
 }
