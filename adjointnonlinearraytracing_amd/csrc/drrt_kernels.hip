@@ -1601,7 +1601,8 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
 #define DRRT_RING_CAP 1250          // slots per wave (10000 B): 4 blocks of 4 waves per CU fill the 160 KiB of LDS
 #endif
 #ifndef DRRT_RING_SLACK
-#define DRRT_RING_SLACK 8           // slots of room along the dominant travel axis when the window is fitted
+#define DRRT_RING_SLACK 4           // slots of room along the dominant travel axis when the window is fitted (six rotated views,
+                                    // same box: 4 -> 10.3 ms, 8 -> 10.5, 12 -> 10.9; 3 waves per SIMD with 1660 slots: 11.9)
 #endif
 constexpr int kRingCap = DRRT_RING_CAP;
 struct Ring {                      // wave-uniform

@@ -150,3 +150,25 @@ def test_q16_params_host_side(lib):
     assert abs(out[0] + E / 16) < 1e-6 and abs(out[1] - 1.125 * E / 65535) < 1e-9 and out[2] == 2.0 ** -14
     assert h.drrt_q16_params((C.c_int * 3)(4, 9, 5), C.c_float(0.5), out) == 0 and abs(out[0] + 4.0 / 16) < 1e-7
     assert h.drrt_q16_params((C.c_int * 3)(4, 0, 5), C.c_float(0.5), out) < 0
+
+
+def test_options_context_manager_is_per_thread():
+    """drrt.using(...) overrides the options of the calling thread only, nests, and restores; the module-level
+    `options` stays the process default."""
+    import threading
+    from adjointnonlinearraytracing_amd import _lib, drrt
+    base = drrt._flags(adjoint=True)
+    seen = {}
+
+    def other():
+        seen["other"] = drrt._flags(adjoint=True)
+
+    with drrt.using(sort_rays=False, corrected_h=True, adjoint_window="ring"):
+        inner = drrt._flags(adjoint=True)
+        t = threading.Thread(target=other); t.start(); t.join()
+        with drrt.using(adjoint_window="box"):
+            nested = drrt._flags(adjoint=True)
+        assert drrt._flags(adjoint=True) == inner
+    assert drrt._flags(adjoint=True) == base == seen["other"]
+    assert inner & _lib.FLAG_RING_WINDOW and inner & _lib.FLAG_CORRECTED_H and not inner & _lib.FLAG_SORT_RAYS
+    assert nested & _lib.FLAG_STATIC_WINDOW and not nested & _lib.FLAG_RING_WINDOW and nested & _lib.FLAG_CORRECTED_H

@@ -716,10 +716,11 @@ def test_failed_ray_warning_is_asynchronous_but_not_lost(gpu, drrt_mod, capsys):
 
 @pytest.mark.parametrize("kind,R,step_res", [("luneburg", 65, 2), ("smooth", 33, 0.7), ("smooth", 5, 1.3)])
 def test_adjoint_kernel_variants_agree(gpu, oracle, drrt_mod, kind, R, step_res):
-    """The three window kernels of drrt_backtrace_f32 -- k_backtrace_flat (default), k_backtrace_win with the
-    software-pipelined loop (DRRT_FLAG_LEGACY_ADJOINT) and without it (+ DRRT_FLAG_NO_PIPELINE) -- run the same per-ray
-    arithmetic (adj_sample / adj_contrib): equal step counts, gradients equal up to the fp32 summation order, and
-    each within 2e-5 of the oracle.  Steps larger than a cell and a 5^3 grid exercise the multi-face jumps and the
+    """The window kernels of drrt_backtrace_f32 -- k_backtrace_flat (box window), k_backtrace_ring (ring window; with the
+    forward's visit order, and with the step hint that starts its rays on the forward march's clock), the device-side
+    choice between the two, both sort keys, k_backtrace_win with the software-pipelined loop (DRRT_FLAG_LEGACY_ADJOINT) and
+    without it (+ DRRT_FLAG_NO_PIPELINE) -- run the same per-ray arithmetic (adj_sample / adj_contrib): equal step counts,
+    gradients equal up to the fp32 summation order, and each within 2e-5 of the oracle.  Steps larger than a cell and a 5^3 grid exercise the multi-face jumps and the
     clamped boundary cells; unsorted rays exercise the global-atomic fallback."""
     import ctypes as C
     from adjointnonlinearraytracing_amd import _lib
@@ -742,14 +743,27 @@ def test_adjoint_kernel_variants_agree(gpu, oracle, drrt_mod, kind, R, step_res)
     p = lambda t: C.c_void_p(t.data_ptr())
     rif_flat = rif.reshape(-1).contiguous()
     grads = {}
-    for name, fl in (("flat", 0), ("win_pipe", _lib.FLAG_LEGACY_ADJOINT), ("win", _lib.FLAG_LEGACY_ADJOINT | _lib.FLAG_NO_PIPELINE)):
-        for sort in (1, 0):
-            flags = fl | sort
+    # the forward march's visit order and per-ray iteration counts, as a binding would hand them to the adjoint
+    fsteps = getattr(drrt_mod.last_order, "drrt_steps", None)
+    assert drrt_mod.last_order is not None and fsteps is not None and fsteps.numel() == n
+    variants = [("flat", _lib.FLAG_STATIC_WINDOW), ("auto", 0), ("ring", _lib.FLAG_RING_WINDOW),
+                ("ring_chord", _lib.FLAG_RING_WINDOW | _lib.FLAG_CHORD_KEY), ("flat_chord", _lib.FLAG_STATIC_WINDOW | _lib.FLAG_CHORD_KEY),
+                ("win_pipe", _lib.FLAG_LEGACY_ADJOINT), ("win", _lib.FLAG_LEGACY_ADJOINT | _lib.FLAG_NO_PIPELINE)]
+    for name, fl in variants:
+        for sort in (1, 0, "hint", "hint+steps"):
+            flags = fl | (0 if sort == 0 else 1)
             ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, rif_flat.numel(), flags)) + 1024, dtype=torch.uint8, device=gpu)
             g = torch.empty_like(rif_flat)
             st = torch.zeros(3, dtype=torch.int64, device=gpu)
+            if isinstance(sort, str):
+                if not name.startswith(("ring", "auto")):
+                    continue
+                lib.drrt_set_order_hint(p(drrt_mod.last_order), n)
+                if sort == "hint+steps":
+                    lib.drrt_set_step_hint(p(fsteps), n)
             _lib.check(lib.drrt_backtrace_f32(p(rif_flat), rif_flat.numel(), res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(g), p(st),
                                               p(ws), ws.numel(), flags, None))
+            assert lib.drrt_order_hint_pending() == 0                       # both hints are consumed by the call
             torch.cuda.synchronize()
             assert int(st[0]) == ob["steps_total"], (name, sort)
             assert cases.rel_l2(g.cpu().numpy(), ob["grad"]) <= 2e-5, (name, sort)

@@ -93,3 +93,27 @@ def test_multires_opt_fused_equals_literal(gpu, tmp_path):
     assert torch.allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-6)
     assert np.allclose(out[True][1], out[False][1], rtol=1e-5)
     assert float(out[True][0].min()) >= 1.0
+
+
+@pytest.mark.gpu
+def test_masked_adam_step_is_visible_to_autograd(gpu):
+    """MaskedAdam writes the parameter through a raw pointer; it must bump the tensor's version counter like any in-place
+    torch op, because the tracer's save_for_backward check and the pair-copy reuse token key on it: a retained-graph
+    backward AFTER step() has to raise (as it does with torch.optim.Adam) instead of pairing the new grid with the exit
+    rays -- and the pair copy -- of the old one."""
+    from adjointnonlinearraytracing_amd import optimizer, tracer
+    R = 17
+    h = 1.0 / (R - 1); ds = h / 2
+    n = (1.0 + 0.1 * torch.rand(R, R, R, device=gpu)).requires_grad_(True)
+    x = torch.rand(256, 3, device=gpu) * 0.8 + 0.1
+    x[:, 1] = -0.3 * ds
+    v = torch.zeros(256, 3, device=gpu); v[:, 1] = 1.0
+    opto = optimizer.MaskedAdam([n], lr=1e-2)
+    xt, vt = tracer.BackTracerC.apply(n, x, v, h, ds)
+    loss = (xt ** 2).sum()
+    ver = n._version
+    loss.backward(retain_graph=True)
+    opto.step()
+    assert n._version > ver
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()

@@ -306,3 +306,22 @@ def test_sensor_frame_on_host_and_on_device_agree(gpu):
             assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(a))), k
         else:
             assert torch.equal(a, b), k
+
+
+@pytest.mark.gpu
+def test_sdf_vals_refuse_what_they_cannot_differentiate(gpu):
+    """The fused texture lookups return gradients of the rays only and take ONE plane per call: a texture that requires
+    grad, or per-ray planes that differ, must raise instead of returning a silent zero / using row 0."""
+    from adjointnonlinearraytracing_amd import sensor
+    N = 64
+    x = torch.rand(N, 3, device=gpu); v = torch.zeros(N, 3, device=gpu); v[:, 1] = 1.0
+    tex = torch.rand(16, 16, device=gpu)
+    p = torch.tensor([[0.5, 1.2, 0.5]], device=gpu); n = torch.tensor([[0.0, 1.0, 0.0]], device=gpu)
+    f = sensor.get_sdf_vals_near((x, v), tex, (p, n), 1.0)
+    assert f.shape == (N,)
+    with pytest.raises(RuntimeError, match="not differentiable w.r.t. the texture"):
+        sensor.get_sdf_vals_near((x, v), tex.clone().requires_grad_(True), (p, n), 1.0)
+    pp = p.repeat(N, 1); pp[5, 1] = 1.5
+    with pytest.raises(RuntimeError, match="one plane"):
+        sensor.get_sdf_vals_near((x, v), tex, (pp, n.repeat(N, 1)), 1.0)
+    assert torch.equal(sensor.get_sdf_vals_near((x, v), tex, (p.repeat(N, 1), n.repeat(N, 1)), 1.0), f)   # equal rows are fine
