@@ -2065,7 +2065,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
             if (old_regular) {
               const int ddx = ix - oix, ddy = iy - oiy, ddz = iz - oiz;
               const bool unit = ((unsigned)(ddx + 1) <= 2u) & ((unsigned)(ddy + 1) <= 2u) & ((unsigned)(ddz + 1) <= 2u);
-              if (regular & unit & (old_lidx >= 0) & (experiment != 1) & (experiment != 4)) {
+              if (regular & unit & (experiment != 1) & (experiment != 4)) {
                 // one, two or three faces crossed: one crossing after the other (x, y, z), each emits the face left behind
                 // and carries the shared one; the later ones hand over zeros where the earlier ones cleared
                 if (ABL && dbg) {
@@ -2074,15 +2074,29 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
                   if (!pre) ++ev_nopre;
                 }
                 int cur = old_lidx;
+                int gcur = old_base;                     // flat grid index of the (intermediate) cell: the grid-side twin of `cur`
+                const bool inw = old_lidx >= 0;          // a lane the window does not hold hands the same faces to the grid
                 bool out = false;
-                crossed = true;
+                crossed = inw;
+                // the four corners of a face straight to the grid (zeros -- corners an earlier crossing cleared -- are skipped)
+                auto face_to_grid = [&](int gbase, int gp, int gq, float e0, float e1, float e2, float e3) {
+                  if (experiment == 2) return;
+                  if (ABL && dbg) ++ev_glob;
+                  float* g = a.grad + gbase;
+                  if (e0 != 0.f) atomic_add_f32(g, e0);
+                  if (e1 != 0.f) atomic_add_f32(g + gp, e1);
+                  if (e2 != 0.f) atomic_add_f32(g + gq, e2);
+                  if (e3 != 0.f) atomic_add_f32(g + gq + gp, e3);
+                };
                 if (ddx != 0) {
                   const bool fwd = ddx > 0;
                   const float e0 = fwd ? p00.x : p00.y, e1 = fwd ? p10.x : p10.y, e2 = fwd ? p01.x : p01.y, e3 = fwd ? p11.x : p11.y;
                   p00 = fwd ? f2{p00.y, 0.f} : f2{0.f, p00.x}; p10 = fwd ? f2{p10.y, 0.f} : f2{0.f, p10.x};
                   p01 = fwd ? f2{p01.y, 0.f} : f2{0.f, p01.x}; p11 = fwd ? f2{p11.y, 0.f} : f2{0.f, p11.x};
-                  out |= ring_cross<ABL>(win, experiment, pre, 0, fwd, cur, sx, sy, sz, R.nx, R.ny, R.nz, 1, R.sy, R.sz, ix, R.ox,
-                                         e0, e1, e2, e3, matched, ev_face, ev_add, dbg);
+                  if (inw) out |= ring_cross<ABL>(win, experiment, pre, 0, fwd, cur, sx, sy, sz, R.nx, R.ny, R.nz, 1, R.sy, R.sz, ix, R.ox,
+                                                  e0, e1, e2, e3, matched, ev_face, ev_add, dbg);
+                  else face_to_grid(gcur + (fwd ? 0 : 1), V.sy, V.sz, e0, e1, e2, e3);
+                  gcur += ddx;
                 }
                 if (ddy != 0) {
                   const bool fwd = ddy > 0;
@@ -2090,8 +2104,10 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
                   const f2 ka = fwd ? p10 : p00, kb = fwd ? p11 : p01;
                   p00 = fwd ? ka : f2{0.f, 0.f}; p01 = fwd ? kb : f2{0.f, 0.f};
                   p10 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
-                  out |= ring_cross<ABL>(win, experiment, pre, 1, fwd, cur, sy, sx, sz, R.ny, R.nx, R.nz, R.sy, 1, R.sz, iy, R.oy,
-                                         ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
+                  if (inw) out |= ring_cross<ABL>(win, experiment, pre, 1, fwd, cur, sy, sx, sz, R.ny, R.nx, R.nz, R.sy, 1, R.sz, iy, R.oy,
+                                                  ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
+                  else face_to_grid(gcur + (fwd ? 0 : V.sy), 1, V.sz, ea.x, ea.y, eb.x, eb.y);
+                  gcur += fwd ? V.sy : -V.sy;
                 }
                 if (ddz != 0) {
                   const bool fwd = ddz > 0;
@@ -2099,13 +2115,16 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
                   const f2 ka = fwd ? p01 : p00, kb = fwd ? p11 : p10;
                   p00 = fwd ? ka : f2{0.f, 0.f}; p10 = fwd ? kb : f2{0.f, 0.f};
                   p01 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
-                  out |= ring_cross<ABL>(win, experiment, pre, 2, fwd, cur, sz, sx, sy, R.nz, R.nx, R.ny, R.sz, 1, R.sy, iz, R.oz,
-                                         ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
+                  if (inw) out |= ring_cross<ABL>(win, experiment, pre, 2, fwd, cur, sz, sx, sy, R.nz, R.nx, R.ny, R.sz, 1, R.sy, iz, R.oz,
+                                                  ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
+                  else face_to_grid(gcur + (fwd ? 0 : V.sz), 1, V.sy, ea.x, ea.y, eb.x, eb.y);
                 }
-                used_lds = true;
-                lidx = out ? -1 : cur;                   // stepped ahead of the window by one cell: ask it to follow
-                miss = out;
-                relocate = false;
+                if (inw) {
+                  used_lds = true;
+                  lidx = out ? -1 : cur;                 // stepped ahead of the window by one cell: ask it to follow
+                  miss = out;
+                  relocate = false;
+                }
               } else {
                 // out of a cell the window does not hold, into or out of a clamped cell, a jump over more than one cell: all eight
                 if (ABL && dbg) { ++ev_all8; ev_all8g += old_lidx < 0; }

@@ -244,7 +244,7 @@ class _TexGet(torch.autograd.Function):
             # gradients of the rays -- say so instead of handing back a silent zero
             raise RuntimeError("get_sdf_vals_*: the fused operator is not differentiable w.r.t. the texture; pass "
                                "d_tex.detach() (the experiments optimise the volume, not the measured texture)")
-        _single_plane(p, n, t1, t2)
+        _single_plane(p, n)            # (t1, t2 of get_tan_vecs are set in row 0 only, as in the reference)
         dev = x.device
         with torch.cuda.device(dev):
             x_ = x.detach().to(torch.float32).contiguous()
