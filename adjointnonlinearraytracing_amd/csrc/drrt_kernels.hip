@@ -1604,6 +1604,9 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
 #define DRRT_RING_SLACK 4           // slots of room along the dominant travel axis when the window is fitted (six rotated views,
                                     // same box: 4 -> 10.3 ms, 8 -> 10.5, 12 -> 10.9; 3 waves per SIMD with 1660 slots: 11.9)
 #endif
+#ifndef DRRT_RING_GROW
+#define DRRT_RING_GROW 0
+#endif
 constexpr int kRingCap = DRRT_RING_CAP;
 struct Ring {                      // wave-uniform
   int nx, ny, nz;                  // slots per axis (>= 2)
@@ -1980,6 +1983,15 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
           int nx = ex + 2 + (int)((float)DRRT_RING_SLACK * fabsf(dx_) * inv_dm + 0.5f);
           int ny = ey + 2 + (int)((float)DRRT_RING_SLACK * fabsf(dy_) * inv_dm + 0.5f);
           int nz = ez + 2 + (int)((float)DRRT_RING_SLACK * fabsf(dz_) * inv_dm + 0.5f);
+#if DRRT_RING_GROW > 0
+          // spare capacity: room on every axis, so that a bundle that widens (the adjoint leaves a focus) is not re-fitted at once
+          int grown = 0;
+#pragma unroll 1
+          for (; grown < DRRT_RING_GROW && (nx + 1) * (ny + 1) * (nz + 1) <= kRingCap; ++grown) { ++nx; ++ny; ++nz; }
+          const int gh = grown >> 1;                       // half of it behind the rays
+#else
+          const int gh = 0;
+#endif
           nx = uni(min(nx, V.W)); ny = uni(min(ny, V.H)); nz = uni(min(nz, V.D));
           ex = min(ex, nx); ey = min(ey, ny); ez = min(ez, nz);
 #pragma unroll 1
@@ -1991,7 +2003,8 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
           }
           R.nx = nx; R.ny = ny; R.nz = nz; R.sy = nx; R.sz = nx * ny;
           // the spare slots lie ahead of the rays
-          int ox = dx_ < 0.f ? x0 - (nx - ex) : x0, oy = dy_ < 0.f ? y0 - (ny - ey) : y0, oz = dz_ < 0.f ? z0 - (nz - ez) : z0;
+          int ox = dx_ < 0.f ? x0 - (nx - ex) + gh : x0 - gh, oy = dy_ < 0.f ? y0 - (ny - ey) + gh : y0 - gh,
+              oz = dz_ < 0.f ? z0 - (nz - ez) + gh : z0 - gh;
           ox = max(0, min(ox, V.W - nx)); oy = max(0, min(oy, V.H - ny)); oz = max(0, min(oz, V.D - nz));
           R.ox = uni(ox); R.oy = uni(oy); R.oz = uni(oz);
           R.bx = R.by = R.bz = 0;

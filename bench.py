@@ -94,6 +94,9 @@ def parse_args(argv=None):
                     help="skip the `variants` leg (the reference's six rotated views and the shifted plane source)")
     ap.add_argument("--variant-steps", type=int, default=5)
     ap.add_argument("--variants", default="cube6_rotated,plane_shifted", help="comma list of the variants to run")
+    ap.add_argument("--workload", choices=("metric", "cube6_rotated", "plane_shifted"), default="metric",
+                    help="ray set of the MAIN run (default: the metric's plane source).  The other two are the `variants` ray "
+                         "sets run as the main workload -- for profiling them on their own (1 GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
                                                         "to rehearse the multi-rank flow on a 1-GPU box)")
     args = ap.parse_args(argv)
@@ -518,6 +521,15 @@ def run_rank(args) -> int:
 
     def run_mode(mode):
         """-> dict of this rank's measurements for one scaling mode."""
+        if args.workload != "metric":                              # a variant's ray set as the main run (profiling aid)
+            assert world == 1, "--workload other than metric: one GPU"
+            if args.workload == "plane_shifted":
+                pos, vel = (t.to(dev) for t in make_rays_shifted(args.rays, seed=0))
+            else:
+                pos, vel, _ = make_rays_cube6(args.rays, 0, dev)
+            out = bench_rays(pos, vel, args.steps, args.warmup, keep=False)
+            out["mode"] = mode
+            return out
         if mode == "strong":
             gpos, gvel = make_rays(args.rays, seed=0)              # the metric's single ray set, same on every rank
             lo, hi = drrt_dist.shard_bounds(args.rays, rank, world)
@@ -565,7 +577,7 @@ def run_rank(args) -> int:
         ach_fwd = fwd_steps * B_FWD / (ms_fwd * 1e-3) / 1e9
         default_cfg = (R == 256 and n == 1024 * 1024 and world == 1 and not args.no_sort and not args.direct_atomics
                        and not args.experiment and args.pair == "auto" and not args.lds_bricks and not args.fwd_flags
-                       and not args.adj_flags)
+                       and not args.adj_flags and args.workload == "metric")
         pmc, pmc_src = load_pmc() if default_cfg else (None, None)
         pk_adj = pmc_kernel(pmc, "drrt::k_backtrace_flat", "drrt::k_backtrace_win")
         pk_fwd = pmc_kernel(pmc, "drrt::k_trace_flat", "drrt::k_trace<0>")
@@ -583,6 +595,8 @@ def run_rank(args) -> int:
                     f"measured in this run") if pmc_src else None
         shard = (f"the metric's single set of {args.rays} rays split into {world} contiguous shards "
                  f"({n} on rank 0)") if main_mode == "strong" else f"{n} rays per GPU (own seed per rank)"
+        if args.workload != "metric":
+            shard = f"NOT the metric's source: the `{args.workload}` ray set of `variants` ({n} rays)"
         roof = {"bound": "hbm", "kernel": "adjoint march (k_backtrace_flat)", "achieved": ach_adj,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_adj / HBM_PEAK_GBS, "traffic": tr_adj,
                 "traffic_source": src_note, "pmc_source": pmc_src, "pmc_lib_version": pmc_lib, "pmc_stale": pmc_stale,
@@ -618,7 +632,11 @@ def run_rank(args) -> int:
             "roofline_fwd": roof_f,
             "phase_ms": {"sort_avg": m["ms_sort"], "zero_grid": m["ms_zero"],
                          "pair_copy": None if m["ms_quad"] != m["ms_quad"] else m["ms_quad"],
-                         "trace": ms_fwd, "backtrace": ms_adj, "allreduce": m["ms_allreduce"] if use_dist else None},
+                         "trace": ms_fwd, "backtrace": ms_adj, "allreduce": m["ms_allreduce"] if use_dist else None,
+                         # the reduce starts when the adjoint has finished and nothing runs beside it: all of it is exposed
+                         # (the gradient of ANY ray subset is a full grid, so reducing half A under the
+                         # adjoint of half B doubles the bytes on the wire and cannot shorten the step)
+                         "allreduce_exposed": m["ms_allreduce"] if use_dist else None},
             "fwd_only_ray_steps_per_s_per_gpu": fwd_steps / (ms_fwd * 1e-3),
         }
         if "weak" in results and main_mode != "weak":
@@ -627,7 +645,7 @@ def run_rank(args) -> int:
                                    "ms_per_step": w["elapsed"] / args.steps * 1e3, "rays_per_gpu": w["n"],
                                    "phase_ms": {"sort_avg": w["ms_sort"], "trace": w["ms_fwd"], "backtrace": w["ms_adj"],
                                                 "allreduce": w["ms_allreduce"] if use_dist else None}}
-        if world == 1 and not args.no_variants and not args.shard_of:
+        if world == 1 and not args.no_variants and not args.shard_of and args.workload == "metric":
             base_ns = ms_adj * 1e6 / max(adj_steps, 1)
             out["variants"] = {"headline_adj_ns_per_ray_step": base_ns,
                                "headline_fwd_ns_per_ray_step": ms_fwd * 1e6 / max(fwd_steps, 1)}
@@ -635,7 +653,7 @@ def run_rank(args) -> int:
                 v = run_variant(name)
                 v["adj_ns_ratio_to_headline"] = v["adj_ns_per_ray_step"] / base_ns
                 out["variants"][name] = v
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "metric":
             def gpu_subset(sel):
                 """The benchmark's own kernel configuration (same flags as the timed run) on the rays `sel`."""
                 import numpy as np

@@ -57,4 +57,9 @@ drrt.options.pair_grid = "auto"
 drrt.options.legacy_adjoint = True
 probe("4 views, legacy adjoint kernel (10^3 windows)", xs, vs)
 drrt.options.legacy_adjoint = False
-
+with drrt.using(adjoint_window="box"):
+    probe("4 views, box-window adjoint kernel forced", xs, vs)
+with drrt.using(adjoint_window="ring"):
+    probe("4 views, ring-window adjoint kernel forced", xs, vs)
+with drrt.using(chord_key=True):
+    probe("4 views, rounds-1/2 chord sort key", xs, vs)

@@ -2,11 +2,13 @@
 # Profiles `bench.py` on the GPU box: (1) kernel trace + stats, (2)-(4) PMC passes (separate runs, as
 # MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass).  Outputs under
 # gpurun_out/prof_$1/ ; condense with tools/condense_profile.py into profiles/.
-tag=${1:-run}
+# usage: profile_bench.sh TAG [extra bench.py args]   (e.g. `profile_bench.sh r3_cube6 --workload cube6_rotated`)
+tag=${1:-run}; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+# --no-variants: one ray set per profile, so that a kernel's average duration in the stats is that of ONE workload
+B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-variants $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B > $out/bench_trace.json 2> $out/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- $B > $out/bench_fetch.json 2> $out/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- $B > $out/bench_write.json 2> $out/write.err
