@@ -317,6 +317,11 @@ def test_sdf_variants(gpu, oracle, drrt_mod):
         refb = oracle.backtrace(rif, rif.shape, ref["xt"], ref["vt"], dx, dv, h, ds, dtype=np.float32, sdf=sdf)
     assert st["ray_steps"] == refb["steps_total"]
     assert cases.rel_l2(g.cpu().numpy(), refb["grad"]) <= 2e-5
+    for window in ("box", "ring"):                           # both window kernels have the sdf end condition (MODE 1)
+        with drrt_mod.using(adjoint_window=window):
+            gw = T.backtrace_sdf(_t(rif, gpu), _t(sdf, gpu), rif.shape, xt, vt, _t(dx, gpu), _t(dv, gpu), h, ds)
+            assert drrt_mod.read_stats()["ray_steps"] == refb["steps_total"], window
+            assert cases.rel_l2(gw.cpu().numpy(), refb["grad"]) <= 2e-5, window
 
 
 def test_cable_variants(gpu, oracle, drrt_mod):

@@ -13,4 +13,4 @@ timeout -k 10 300 python tools/probe_views.py > $O/probe_views.txt 2> $O/probe_v
 timeout -k 10 300 python tools/profile_sweeps.py > $O/sweeps.txt 2> $O/sweeps.err; echo "sweeps rc=$?"
 timeout -k 10 300 python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 > $O/bench_gloo2.json 2> $O/bench_gloo2.err; echo "gloo2 rc=$?"
 timeout -k 10 300 python bench.py --rays 16777216 --steps 3 --warmup 1 --no-cpu-baseline --no-variants > $O/bench_16M.json 2> $O/bench_16M.err; echo "16M rc=$?"
-tail -2 $O/*.err | cut -c1-300
+for f in $O/*.err; do echo "== $f"; tail -n 2 $f | cut -c1-300; done
