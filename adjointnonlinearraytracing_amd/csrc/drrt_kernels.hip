@@ -1607,9 +1607,17 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
 #ifndef DRRT_RING_GROW
 #define DRRT_RING_GROW 0
 #endif
-#ifndef DRRT_RING_PRE_PCT
-#define DRRT_RING_PRE_PCT 75        // pre-reduction stays on while at least this percentage of the crossing lanes find their pair partner
-                                    // (six rotated views, same box: 25 -> 10.85 ms, 50 -> 10.5, 75 -> 10.3, never -> 10.55)
+#ifndef DRRT_RING_SIMPLE
+#define DRRT_RING_SIMPLE 0
+#endif
+#ifndef DRRT_RING_FLUSH_BATCH
+#define DRRT_RING_FLUSH_BATCH 2     // LDS exchanges in flight per lane in a flush (4 costs ~10 more VGPRs at the kernel's pressure peak)
+#endif
+#ifndef DRRT_RING_DENSE_PCT
+#define DRRT_RING_DENSE_PCT 50      // a wave's bundle counts as dense while at least this percentage of its lanes share their cell with
+                                    // their pair partner (sampled every 16th iteration).  Same box, ring kernel forced, ms of the adjoint
+                                    // on: six rotated views / metric / 4-view tomography set (tools/probe_views.py):
+                                    //   never sparse 9.9 / 5.9 / 5.0;  50 % -> 9.0 / 5.9 / 5.2;  70 % -> 8.9 / 6.8 / 5.7;  always sparse 8.9 / 8.8 / 5.9
 #endif
 constexpr int kRingCap = DRRT_RING_CAP;
 struct Ring {                      // wave-uniform
@@ -1658,7 +1666,7 @@ __device__ __forceinline__ void ring_flush(win_t* win, const Ring& R, int g0, in
   const int e01 = e0 * e1, total = e01 * e2;
   const float inv0 = 1.0f / (float)e0, inv01 = 1.0f / (float)e01;
   const int r0 = g0 - (A == 0 ? R.ox : (A == 1 ? R.oy : R.oz));       // first layer, relative to the low corner
-  constexpr int kBatch = 4;
+  constexpr int kBatch = DRRT_RING_FLUSH_BATCH;
 #pragma unroll 1
   for (int e_base = 0; e_base < total; e_base += kWave * kBatch) {
     win_t v[kBatch];
@@ -1781,30 +1789,30 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
   float wx = 0.f, wy = 0.f, wz = 0.f;
   bool interior = false, regular = false;
   int lidx = -1;
-  f4 q0 = f4{0.f, 0.f, 0.f, 0.f}, q1 = q0;
-  int tbase = -1;
+  f4 q0 = f4{0.f, 0.f, 0.f, 0.f}, q1 = q0;             // the taps of cell `base` when it is strictly interior (gathered one step ahead)
   f2 p00 = f2{0.f, 0.f}, p10 = p00, p01 = p00, p11 = p00;
   bool miss = false;                                           // the lane wants the window to come to it
+  bool have_taps = false;
   const TapRows Rw = tap_rows<PAIR>(V);
   auto step_locate = [&](int& nbase, bool& nregular) {
     s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);
     const float fx = s.x * V.inv_h, fy = s.y * V.inv_h, fz = s.z * V.inv_h;
     ix = cvt_floor_i32(fx); iy = cvt_floor_i32(fy); iz = cvt_floor_i32(fz);
+    const bool held = interior & have_taps;                  // the lane holds the taps of the (interior) cell `base`
     interior = (((unsigned)ix - 1u) < V.lx) & (((unsigned)iy - 1u) < V.ly) & (((unsigned)iz - 1u) < V.lz);
     if (interior) {
       wx = __builtin_amdgcn_fractf(fx); wy = __builtin_amdgcn_fractf(fy); wz = __builtin_amdgcn_fractf(fz);
       nbase = mad24(iz, V.sz, mad24(iy, V.sy, ix));
       nregular = true;
-      if (nbase != tbase) {
+      if (!(held & (nbase == base))) {
         __builtin_assume(nbase >= 0 && nbase < (1 << 29));
         gather_rows<PAIR>(Rw, tap_offset<PAIR>(nbase), q0, q1);
-        tbase = nbase;
       }
+      have_taps = true;
     } else {
       const Cell cb = locate(V, s.x, s.y, s.z);
       wx = cb.wx; wy = cb.wy; wz = cb.wz; ix = cb.ix; iy = cb.iy; iz = cb.iz; nbase = cb.base;
       nregular = (cb.ox == 1) & (cb.oy == V.sy) & (cb.oz == V.sz);
-      tbase = -1;
     }
   };
   // Step hint (a.fsteps: the iteration count of the forward march that produced each exit ray): the rays of a wave
@@ -1836,10 +1844,13 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
   bool dirty = false;
   int cooldown = 0;
   unsigned n_flush = 0, n_slide = 0, n_fit = 0;
-  // pre-reduction on / off, wave by wave: lanes that took part / that found their pair partner since the last decision
-  bool pre = true;
-  unsigned pr_lanes = 0, pr_hits = 0;
-  int pre_off = 0;
+  // Dense or sparse bundle?  Wave by wave, re-decided every 32 iterations from how many lanes share their cell with their
+  // pair partner.  Dense: faces carried over across crossings, pair / quad pre-reduction (many lanes add to the same slots).
+  // Sparse: all eight corners handed over on every leave -- 8 instead of ~4 LDS adds per leave, but none of the per-axis
+  // blocks, which for rays oblique to the grid all run on every step (measured on the six rotated views: 535 -> 382 VALU
+  // instructions per wave-step, 10.5 -> 8.9 ms; on the metric's dense bundles the same choice costs 6.4 -> 8.8 ms).
+  const bool pre = true;
+  bool sparse = DRRT_RING_SIMPLE != 0;
   unsigned ev_face = 0, ev_add = 0, ev_glob = 0, ev_all8 = 0, ev_wsteps = 0, ev_multi = 0;
   unsigned ev_nofit = 0, ev_service = 0, ev_left = 0, ev_vol = 0, ev_all8g = 0, ev_nopre = 0;   // debug: see the end of the kernel
 
@@ -2022,14 +2033,14 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
     } else if (cooldown > 0) {
       --cooldown;
     }
-    // pre-reduction: worth its ~30 instructions per block only while lanes find partners
-    if (pre) {
-      if (pr_lanes >= 512u) { if (pr_hits * 100u < pr_lanes * (unsigned)DRRT_RING_PRE_PCT) { pre = false; pre_off = 64; } pr_lanes = pr_hits = 0u; }
-    } else if (--pre_off <= 0) {
-      pre = true;
+    if (DRRT_RING_SIMPLE == 0 && (it & 15) == 15) {          // a sample of one iteration in 16 (scalar arithmetic only)
+      const bool on = s.active & regular;
+      const int pb = __builtin_amdgcn_update_dpp(-1, base, 0xB1, 0xF, 0xF, false);   // the pair partner's cell (quad_perm [1,0,3,2])
+      const int lanes = __popcll(__ballot(on)), hits = __popcll(__ballot(on & (pb == base)));
+      sparse = uni(hits * 100) < uni(lanes * DRRT_RING_DENSE_PCT);
     }
     bool used_lds = false;
-    bool crossed = false, matched = false;                   // this step: the lane crossed faces / found its pair partner
+    bool matched = false;                                    // (pair-partner match of this step's crossings: debug counters only)
     if (s.active) {
       if (!interior) taps_set<PAIR>(fetch(V.data, locate(V, s.x, s.y, s.z)), q0, q1);   // boundary cell (clamped neighbours): fetched here, not ahead
       Cell c;
@@ -2061,10 +2072,16 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
           atomic_add_f32(g + cb.oz + cb.oy, w.c011);     atomic_add_f32(g + cb.oz + cb.oy + cb.ox, w.c111);
         }
         const int old_base = base, old_lidx = lidx;
-        const int oix = ix, oiy = iy, oiz = iz;
         const bool old_regular = regular;
         int nbase; bool nregular;
-        step_locate(nbase, nregular);
+        int dpack;                                         // the move in cells, one VGPR: (ddx + 1) | (ddy + 1) << 2 | (ddz + 1) << 4, or -1
+        {
+          const int oix = ix, oiy = iy, oiz = iz;
+          step_locate(nbase, nregular);
+          const int ddx = ix - oix, ddy = iy - oiy, ddz = iz - oiz;
+          const bool unit = ((unsigned)(ddx + 1) <= 2u) & ((unsigned)(ddy + 1) <= 2u) & ((unsigned)(ddz + 1) <= 2u);
+          dpack = unit ? ((ddx + 1) | ((ddy + 1) << 2) | ((ddz + 1) << 4)) : -1;
+        }
         // lambda / mu (:434-435)
         const float hxy = m.hxy * V.inv_h2, hxz = m.hxz * V.inv_h2, hyz = m.hyz * V.inv_h2;
         const float hmx = fmaf(hxz, s.mz, hxy * s.my);
@@ -2080,40 +2097,25 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
           if (nbase != old_base || regular != old_regular) {
             bool relocate = true;                        // the new cell still has to be placed in the window
             if (old_regular) {
-              const int ddx = ix - oix, ddy = iy - oiy, ddz = iz - oiz;
-              const bool unit = ((unsigned)(ddx + 1) <= 2u) & ((unsigned)(ddy + 1) <= 2u) & ((unsigned)(ddz + 1) <= 2u);
-              if (regular & unit & (experiment != 1) & (experiment != 4)) {
+              const bool unit = dpack >= 0;
+              const int ddx = (dpack & 3) - 1, ddy = ((dpack >> 2) & 3) - 1, ddz = ((dpack >> 4) & 3) - 1;
+              if (!sparse && (regular & unit & (old_lidx >= 0) & (experiment != 1) & (experiment != 4))) {
                 // one, two or three faces crossed: one crossing after the other (x, y, z), each emits the face left behind
                 // and carries the shared one; the later ones hand over zeros where the earlier ones cleared
                 if (ABL && dbg) {
                   const int nax = (__ballot(ddx != 0) != 0ull) + (__ballot(ddy != 0) != 0ull) + (__ballot(ddz != 0) != 0ull);
                   if (lane == __ffsll((long long)__ballot(true)) - 1) ev_multi += nax >= 2;
-                  if (!pre) ++ev_nopre;
+                  if (sparse) ++ev_nopre;
                 }
                 int cur = old_lidx;
-                int gcur = old_base;                     // flat grid index of the (intermediate) cell: the grid-side twin of `cur`
-                const bool inw = old_lidx >= 0;          // a lane the window does not hold hands the same faces to the grid
                 bool out = false;
-                crossed = inw;
-                // the four corners of a face straight to the grid (zeros -- corners an earlier crossing cleared -- are skipped)
-                auto face_to_grid = [&](int gbase, int gp, int gq, float e0, float e1, float e2, float e3) {
-                  if (experiment == 2) return;
-                  if (ABL && dbg) ++ev_glob;
-                  float* g = a.grad + gbase;
-                  if (e0 != 0.f) atomic_add_f32(g, e0);
-                  if (e1 != 0.f) atomic_add_f32(g + gp, e1);
-                  if (e2 != 0.f) atomic_add_f32(g + gq, e2);
-                  if (e3 != 0.f) atomic_add_f32(g + gq + gp, e3);
-                };
                 if (ddx != 0) {
                   const bool fwd = ddx > 0;
                   const float e0 = fwd ? p00.x : p00.y, e1 = fwd ? p10.x : p10.y, e2 = fwd ? p01.x : p01.y, e3 = fwd ? p11.x : p11.y;
                   p00 = fwd ? f2{p00.y, 0.f} : f2{0.f, p00.x}; p10 = fwd ? f2{p10.y, 0.f} : f2{0.f, p10.x};
                   p01 = fwd ? f2{p01.y, 0.f} : f2{0.f, p01.x}; p11 = fwd ? f2{p11.y, 0.f} : f2{0.f, p11.x};
-                  if (inw) out |= ring_cross<ABL>(win, experiment, pre, 0, fwd, cur, sx, sy, sz, R.nx, R.ny, R.nz, 1, R.sy, R.sz, ix, R.ox,
-                                                  e0, e1, e2, e3, matched, ev_face, ev_add, dbg);
-                  else face_to_grid(gcur + (fwd ? 0 : 1), V.sy, V.sz, e0, e1, e2, e3);
-                  gcur += ddx;
+                  out |= ring_cross<ABL>(win, experiment, pre, 0, fwd, cur, sx, sy, sz, R.nx, R.ny, R.nz, 1, R.sy, R.sz, ix, R.ox,
+                                         e0, e1, e2, e3, matched, ev_face, ev_add, dbg);
                 }
                 if (ddy != 0) {
                   const bool fwd = ddy > 0;
@@ -2121,10 +2123,8 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
                   const f2 ka = fwd ? p10 : p00, kb = fwd ? p11 : p01;
                   p00 = fwd ? ka : f2{0.f, 0.f}; p01 = fwd ? kb : f2{0.f, 0.f};
                   p10 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
-                  if (inw) out |= ring_cross<ABL>(win, experiment, pre, 1, fwd, cur, sy, sx, sz, R.ny, R.nx, R.nz, R.sy, 1, R.sz, iy, R.oy,
-                                                  ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
-                  else face_to_grid(gcur + (fwd ? 0 : V.sy), 1, V.sz, ea.x, ea.y, eb.x, eb.y);
-                  gcur += fwd ? V.sy : -V.sy;
+                  out |= ring_cross<ABL>(win, experiment, pre, 1, fwd, cur, sy, sx, sz, R.ny, R.nx, R.nz, R.sy, 1, R.sz, iy, R.oy,
+                                         ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
                 }
                 if (ddz != 0) {
                   const bool fwd = ddz > 0;
@@ -2132,16 +2132,13 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
                   const f2 ka = fwd ? p01 : p00, kb = fwd ? p11 : p10;
                   p00 = fwd ? ka : f2{0.f, 0.f}; p10 = fwd ? kb : f2{0.f, 0.f};
                   p01 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
-                  if (inw) out |= ring_cross<ABL>(win, experiment, pre, 2, fwd, cur, sz, sx, sy, R.nz, R.nx, R.ny, R.sz, 1, R.sy, iz, R.oz,
-                                                  ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
-                  else face_to_grid(gcur + (fwd ? 0 : V.sz), 1, V.sy, ea.x, ea.y, eb.x, eb.y);
+                  out |= ring_cross<ABL>(win, experiment, pre, 2, fwd, cur, sz, sx, sy, R.nz, R.nx, R.ny, R.sz, 1, R.sy, iz, R.oz,
+                                         ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
                 }
-                if (inw) {
-                  used_lds = true;
-                  lidx = out ? -1 : cur;                 // stepped ahead of the window by one cell: ask it to follow
-                  miss = out;
-                  relocate = false;
-                }
+                used_lds = true;
+                lidx = out ? -1 : cur;                   // stepped ahead of the window by one cell: ask it to follow
+                miss = out;
+                relocate = false;
               } else {
                 // out of a cell the window does not hold, into or out of a clamped cell, a jump over more than one cell: all eight
                 if (ABL && dbg) { ++ev_all8; ev_all8g += old_lidx < 0; }
@@ -2159,7 +2156,6 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
       }
     }
     dirty = dirty | (__ballot(used_lds) != 0ull);
-    if (pre) { pr_lanes += (unsigned)__popcll(__ballot(crossed)); pr_hits += (unsigned)__popcll(__ballot(matched)); }
     if (ABL && dbg) ev_wsteps += lane == 0;
   }
   // rays still marching when max_steps ran out keep what their cell has accumulated: hand it over
