@@ -19,7 +19,13 @@ def short(name):
     return name if len(name) < 110 else name[:107] + "..."
 
 
-stats = glob.glob(f"{src}/trace/runc/*_kernel_stats.csv")
+def newest(pattern):
+    """gpurun merges every call's files into the same local directory (one <pid>_ prefix per run): the newest only."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
+stats = newest(f"{src}/trace/runc/*_kernel_stats.csv")
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
@@ -30,7 +36,7 @@ if stats:
                         r["MinNs"], r["MaxNs"]])
 
 pmc = collections.defaultdict(dict)
-for f in glob.glob(f"{src}/pmc_*/runc/*_counter_collection.csv"):
+for f in [g for d in sorted(glob.glob(f"{src}/pmc_*")) for g in newest(f"{d}/runc/*_counter_collection.csv")]:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         if "drrt::" not in r["Kernel_Name"]:
