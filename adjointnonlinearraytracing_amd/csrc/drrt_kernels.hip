@@ -1590,8 +1590,8 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
 //     the earlier ones cleared -- wherever those land, adding 0.0 changes nothing) instead of handing over all eight
 //     corners un-reduced: the per-axis blocks run anyway when a wave's lanes cross different faces, which is every step
 //     for rays oblique to the grid;
-//   * the pair / quad pre-reduction is switched off, wave by wave, while fewer than a quarter of the lanes find a partner
-//     (sparse bundles: 89 % of the lanes added alone, the 30 instructions per block bought nothing);
+//   * dense or sparse, wave by wave: while fewer than half of the lanes share their cell with their pair partner the wave
+//     hands over all eight corners on every leave instead (no per-axis blocks at all; see `sparse` below);
 //   * lanes far from the bundle (a bundle torn apart at the rim of a lens) do not take part in the window's decisions.
 // ---------------------------------------------------------------------------------------------
 #ifndef DRRT_RING_WAVES

@@ -72,6 +72,17 @@ def test_fuzz_against_oracle(gpu, oracle, seed):
             obr = oracle.backtrace(c["rif"], res, c["pos"], c["vel"], c["dx"], c["dv"], h, ds, dtype=np.float32)
             assert sr["ray_steps"] == obr["steps_total"]
             assert cases.grads_agree(gr.cpu().numpy(), obr["grad"])
+            # ---- the same three adjoints on the ring-window kernel, forced (tiny / non-cubic grids, multi-cell steps, rays at
+            # rest or outside, a step hint with wildly different iteration counts when the forward's order is handed over)
+            with drrt.using(adjoint_window="ring"):
+                g2 = T.backtrace(R, res, xt, vt, _t(c["dx"], gpu), _t(c["dv"], gpu), h, ds, order=order)
+                assert drrt.read_stats()["ray_steps"] == ob["steps_total"]
+                assert cases.rel_l2(g2.cpu().numpy(), ob["grad"]) <= 2e-5 or scale < 1e-20
+                gs2 = T.backtrace_sdf(R, S, res, xs, vs, _t(c["dx"], gpu), _t(c["dv"], gpu), h, ds)
+                assert cases.grads_agree(gs2.cpu().numpy(), obs["grad"])
+                gr2 = T.backtrace(R, res, P, V, _t(c["dx"], gpu), _t(c["dv"], gpu), h, ds)
+                assert drrt.read_stats()["ray_steps"] == obr["steps_total"]
+                assert cases.grads_agree(gr2.cpu().numpy(), obr["grad"])
     finally:
         drrt.options.sort_rays = True
         drrt.options.quad_grid = False
