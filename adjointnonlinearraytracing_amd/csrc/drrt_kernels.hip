@@ -2074,8 +2074,10 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
         const int old_base = base, old_lidx = lidx;
         const bool old_regular = regular;
         int nbase; bool nregular;
-        int dpack;                                         // the move in cells, one VGPR: (ddx + 1) | (ddy + 1) << 2 | (ddz + 1) << 4, or -1
-        {
+        int dpack = -1;                                    // the move in cells, one VGPR: (ddx + 1) | (ddy + 1) << 2 | (ddz + 1) << 4, or -1
+        if (sparse) {                                      // (wave-uniform) a sparse bundle does not look at the move
+          step_locate(nbase, nregular);
+        } else {
           const int oix = ix, oiy = iy, oiz = iz;
           step_locate(nbase, nregular);
           const int ddx = ix - oix, ddy = iy - oiy, ddz = iz - oiz;

@@ -471,3 +471,37 @@ def test_metric_workload_runs_on_the_fast_kernels(gpu, D):
     assert float(g.abs().sum()) > 0.0
     assert prof.get("trace", 1e9) < 3.3, prof            # measured 1.07 ms
     assert prof.get("backtrace", 1e9) < 15.0, prof       # measured 4.85 ms
+
+
+@pytest.mark.parametrize("workload", ["metric", "cube6_rotated"])
+def test_bench_workloads_against_the_oracle_at_full_size(gpu, oracle, D, workload):
+    """The two ray sets bench.py times -- the metric's plane source and the reference's six randomly rotated views
+    (core/source.py:398-412,555-563) -- through the drop-in API exactly as the benchmark runs them (sort, pair copy by
+    rule, the forward's order and iteration counts handed to the adjoint, device-side choice of the adjoint kernel: box
+    window for the first, ring window for the second), ALL 1 048 576 rays against the all-cores oracle in the kernels'
+    arithmetic: exit rays bit-exact, step totals equal, rel-L2(dL/dn) <= 2e-5 (src/tracer.cpp:35-100,384-440)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    R, n = 256, 1 << 20
+    span = 1.0; h = span / (R - 1); ds = h / 2
+    rif = bench.make_grid(R, gpu)
+    if workload == "metric":
+        pos, vel = (t.to(gpu) for t in bench.make_rays(n, seed=0))
+    else:
+        pos, vel, _ = bench.make_rays_cube6(n, 0, gpu)
+    T = D.TracerC()
+    res = (R, R, R)
+    xt, vt = T.trace(rif.reshape(-1), res, pos, vel, h, ds)
+    fwd = D.read_stats()
+    order = D.last_order
+    assert order is not None and getattr(order, "drrt_steps", None) is not None
+    ones = torch.ones_like(xt)
+    g = T.backtrace(rif.reshape(-1), res, xt, vt, ones, ones, h, ds, order=order)
+    adj = D.read_stats()
+    threads = max(1, min(len(os.sched_getaffinity(0)), 32))
+    with oracle.arith("factored"):
+        o = oracle.bench_allcores(rif.cpu().numpy(), res, pos.cpu().numpy(), vel.cpu().numpy(), h, ds, threads, want_rays=True)
+    assert np.array_equal(xt.cpu().numpy(), o["xt"]) and np.array_equal(vt.cpu().numpy(), o["vt"])
+    assert fwd["ray_steps"] == o["fwd_steps"] and adj["ray_steps"] == o["adj_steps"]
+    assert cases.rel_l2(g.cpu().numpy(), o["grad"]) <= 2e-5
