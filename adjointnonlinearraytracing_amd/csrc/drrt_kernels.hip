@@ -1607,6 +1607,9 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
 #ifndef DRRT_RING_GROW
 #define DRRT_RING_GROW 0
 #endif
+#ifndef DRRT_RING_SLACK_MIN
+#define DRRT_RING_SLACK_MIN 2       // slots of room on every axis when the window is fitted
+#endif
 #ifndef DRRT_RING_SIMPLE
 #define DRRT_RING_SIMPLE 0
 #endif
@@ -1842,7 +1845,6 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
     miss = regular;
   }
   bool dirty = false;
-  int cooldown = 0;
   unsigned n_flush = 0, n_slide = 0, n_fit = 0;
   // Dense or sparse bundle?  Wave by wave, re-decided every 32 iterations from how many lanes share their cell with their
   // pair partner.  Dense: faces carried over across crossings, pair / quad pre-reduction (many lanes add to the same slots).
@@ -1878,11 +1880,15 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
     }
     return false;
   };
-  // (re-)place every lane in the window
-  auto place_all = [&](bool ok) {
+  // (Re-)place every lane in the window; -> lanes next to the window that it still does not hold.  Nobody keeps asking:
+  // a lane the service could not bring in is placed again by the next service some OTHER lane asks for (a lane asks
+  // when it steps out of the window, not while it stays outside), so a bundle that does not fit costs its outliers'
+  // global atomics, not a futile service per step.
+  auto place_all = [&](bool ok) -> bool {
     bool nearby = false;
     lidx = regular ? ring_locate(R, ix, iy, iz, sx, sy, sz, nearby) : -1;
-    miss = ok & (lidx < 0) & nearby;
+    miss = false;
+    return ok & (lidx < 0) & nearby;
   };
 
   for (int it = 0; it < it_end; ++it) {
@@ -1906,7 +1912,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
     }
     // ---- lanes ahead of (or beside) the window: let it follow them (wave-uniform branch) ----
     const unsigned long long mm = __ballot(s.active & miss);
-    if (mm != 0ull && cooldown == 0) {
+    if (mm != 0ull) {
       const bool ok = s.active & regular;
       const int big = 1 << 28;
       bool settled = false;
@@ -1963,8 +1969,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
             }
           }
         }
-        place_all(ok);
-        settled = __ballot(miss) == 0ull;
+        settled = __ballot(place_all(ok)) == 0ull;
       }
       if (!settled) {
         // (re-)fit: the bounding box of the cells the rays stand on -- of the lanes next to the old window when there is
@@ -1985,7 +1990,12 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
           const float dx_ = -__shfl(s.vx, ref, kWave), dy_ = -__shfl(s.vy, ref, kWave), dz_ = -__shfl(s.vz, ref, kWave);
           const float inv_dm = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f)));
           int ex = x1 - x0 + 2, ey = y1 - y0 + 2, ez = z1 - z0 + 2;             // slots the cells need per axis
-          if (uni((int)(ex * ey * ez > kRingCap)) != 0) {
+          const bool too_big = uni((int)(ex * ey * ez > kRingCap)) != 0;
+          if (too_big && fitted) {
+            // the lanes next to the window do not fit any window together: it stays where it is, they go to the grid
+            if (ABL && dbg) ++ev_nofit;
+          } else {
+          if (too_big) {
             // no window holds them all: a cube of the capacity around the median lane's cell; the others go to the grid
             if (ABL && dbg) ++ev_nofit;
             const int rx = __shfl(ix, ref, kWave), ry = __shfl(iy, ref, kWave), rz = __shfl(iz, ref, kWave);
@@ -1995,9 +2005,9 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
             ex = x1 - x0 + 2; ey = y1 - y0 + 2; ez = z1 - z0 + 2;
           }
           if (dirty) { ring_flush<2>(win, R, R.oz, R.nz, a.grad, V, lane, experiment == 2); dirty = false; ++n_flush; }
-          int nx = ex + 2 + (int)((float)DRRT_RING_SLACK * fabsf(dx_) * inv_dm + 0.5f);
-          int ny = ey + 2 + (int)((float)DRRT_RING_SLACK * fabsf(dy_) * inv_dm + 0.5f);
-          int nz = ez + 2 + (int)((float)DRRT_RING_SLACK * fabsf(dz_) * inv_dm + 0.5f);
+          int nx = ex + DRRT_RING_SLACK_MIN + (int)((float)DRRT_RING_SLACK * fabsf(dx_) * inv_dm + 0.5f);
+          int ny = ey + DRRT_RING_SLACK_MIN + (int)((float)DRRT_RING_SLACK * fabsf(dy_) * inv_dm + 0.5f);
+          int nz = ez + DRRT_RING_SLACK_MIN + (int)((float)DRRT_RING_SLACK * fabsf(dz_) * inv_dm + 0.5f);
 #if DRRT_RING_GROW > 0
           // spare capacity: room on every axis, so that a bundle that widens (the adjoint leaves a focus) is not re-fitted at once
           int grown = 0;
@@ -2025,13 +2035,11 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
           R.bx = R.by = R.bz = 0;
           fitted = true; ++n_fit;
           if (ABL && dbg) ev_vol += (unsigned)(nx * ny * nz);
-          place_all(ok);
+          const bool left = place_all(ok);
+          if (ABL && dbg) ev_left += (unsigned)__popcll(__ballot(left));
+          }
         }
       }
-      if (ABL && dbg) ev_left += (unsigned)__popcll(__ballot(miss));
-      cooldown = (__ballot(miss) != 0ull) ? 4 : 0;                            // lanes the window cannot reach: do not thrash
-    } else if (cooldown > 0) {
-      --cooldown;
     }
     if (DRRT_RING_SIMPLE == 0 && (it & 15) == 15) {          // a sample of one iteration in 16 (scalar arithmetic only)
       const bool on = s.active & regular;
@@ -2151,7 +2159,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
             if (relocate) {
               bool nearby = false;
               lidx = regular ? ring_locate(R, ix, iy, iz, sx, sy, sz, nearby) : -1;
-              miss = regular & (lidx < 0) & (nearby | !fitted);
+              miss = regular & (lidx < 0) & ((nearby & (old_lidx >= 0)) | !fitted);   // stepped out of the window: ask it to follow
             }
           }
         }
