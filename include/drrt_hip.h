@@ -88,10 +88,13 @@ extern "C" {
 #define DRRT_FLAG_CHORD_KEY 0x800000u      /* with SORT_RAYS (A-B measurement; same results): the rounds-1/2 sort key (6-D Morton interleave of the
                                               chord end points) instead of the light-field key (direction cell + Hilbert index of the
                                               transverse offset, csrc/drrt_sort.hip) */
-#define DRRT_FLAG_RING_WINDOW 0x1000000u   /* backtrace, backtrace_sdf: the ring-window adjoint kernel (k_backtrace_ring: the wave's LDS window is
-                                              addressed modulo its size and follows the rays; each voxel is flushed once) */
-#define DRRT_FLAG_STATIC_WINDOW 0x400000u  /* backtrace (A-B measurement; same results up to fp32 summation order): always the
-                                             kernel with compile-time 9^3 gradient windows, no per-call bundle classification */
+/* Which adjoint kernel runs (same results up to fp32 summation order).  Default: with a visit order and a
+ * drrt_workspace_bytes_grid() workspace the 64-ray bundles of the call are classified on the device and either the box-window
+ * kernel (compact bundles) or the ring-window kernel (sparse views, views oblique to the grid) runs; the two flags force one. */
+#define DRRT_FLAG_RING_WINDOW 0x1000000u   /* backtrace, backtrace_sdf: always the ring-window kernel (k_backtrace_ring: the wave's LDS window is
+                                              addressed modulo its size and follows the rays; each voxel is flushed once; honours the step hint) */
+#define DRRT_FLAG_STATIC_WINDOW 0x400000u  /* backtrace, backtrace_sdf: always the box-window kernel (k_backtrace_flat, compile-time 9^3 gradient
+                                              windows), no per-call bundle classification */
 #define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace, backtrace_sdf (A-B measurement; same results up to fp32 summation order): the round-1
                                              window kernel k_backtrace_win instead of the reorganised k_backtrace_flat */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): uint64 counters are
@@ -158,8 +161,8 @@ DRRT_API const char* drrt_version(void);
  * where the exit rays alone (a focus, a caustic) say nothing about the bundle they came from.   */
 DRRT_API const uint32_t* drrt_last_order(size_t* n_out);
 DRRT_API void drrt_set_order_hint(const uint32_t* order, size_t n);
-/* Length of the hint currently armed on this host thread (0 = none): lets a binding assert that no hint
- * survives a call. */
+/* Length of the hint currently armed on this host thread -- the order hint's, or the step hint's (below) when only
+ * that one is armed; 0 = neither: lets a binding assert that no hint survives a call. */
 DRRT_API size_t drrt_order_hint_pending(void);
 /* ---- step hint (optimisation hint of the same kind; results do not depend on it) ---------------------------------
  * A forward march (drrt_trace_f32 / _f16io / _q16io / drrt_trace_pln_f32 called with a workspace) leaves the number of
