@@ -33,6 +33,7 @@ FLAG_Q16_POS_ONLY = 0x200000
 FLAG_STATIC_WINDOW = 0x400000
 FLAG_CHORD_KEY = 0x800000
 FLAG_RING_WINDOW = 0x1000000
+FLAG_DISPATCH_IN_ORDER = 0x2000000
 ADAM_MASK_BOUNDARY, ADAM_CLAMP_MIN = 1, 2
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4

@@ -95,6 +95,10 @@ extern "C" {
                                               addressed modulo its size and follows the rays; each voxel is flushed once; honours the step hint) */
 #define DRRT_FLAG_STATIC_WINDOW 0x400000u  /* backtrace, backtrace_sdf: always the box-window kernel (k_backtrace_flat, compile-time 9^3 gradient
                                               windows), no per-call bundle classification */
+#define DRRT_FLAG_DISPATCH_IN_ORDER 0x2000000u /* trace, trace_pln, backtrace, backtrace_sdf (A-B measurement; forward bit-identical, adjoint the same
+                                         up to fp32 summation order): block b of a launch marches block b of the visit order.  Default
+                                         with a visit order: each of the chip's 8 XCDs (own L2; blocks are dealt to them round-robin)
+                                         takes a contiguous run of the visit order, so neighbouring bundles share one L2 */
 #define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace, backtrace_sdf (A-B measurement; same results up to fp32 summation order): the round-1
                                              window kernel k_backtrace_win instead of the reorganised k_backtrace_flat */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): uint64 counters are

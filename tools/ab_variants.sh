@@ -16,7 +16,7 @@ for f in sorted(glob.glob(sys.argv[1]+'/*.json')):
     try:
         d=json.load(open(f)); n=f.split('/')[-1].rsplit('_',1)[0]
         v=d.get('variants',{})
-        r[n].append('head %.2f | '%d['phase_ms']['backtrace'] + ' | '.join('%s adj %.2f (%.1e)'%(k[:5],x['backtrace'],x['grad_rel_l2_vs_direct_atomics']) for k,x in v.items() if isinstance(x,dict)))
+        r[n].append('head %.3f+%.3f | '%(d['phase_ms']['trace'],d['phase_ms']['backtrace']) + ' | '.join('%s %.2f+%.2f (%.0e)'%(k[:5],x['trace'],x['backtrace'],x['grad_rel_l2_vs_direct_atomics']) for k,x in v.items() if isinstance(x,dict)))
     except Exception as e: print(f,'unreadable',e)
 for n,v in r.items(): print(n.ljust(8), ' || '.join(v))
 PY

@@ -15,4 +15,4 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write 
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $out/pmc_sq -- $B > $out/bench_sq.json 2> $out/sq.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $out/pmc_tcc -- $B > $out/bench_tcc.json 2> $out/tcc.err
 find $out -name "*.csv" | head -30
-tail -2 $out/*.err | cut -c1-200
+for f in $out/*.err; do tail -n 2 "$f" | cut -c1-200; done
