@@ -166,6 +166,10 @@ __global__ void __launch_bounds__(256) k_lightfield_keys(Vol V, size_t n, const 
 
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
+// (rocPRIM picks the algorithm by size: up to radix_sort_config<>::merge_sort_limit = 1M items a block sort + merge passes
+// -- 21 launches of 5-9 us for the metric's 1 048 576 rays, 0.167 ms --, Onesweep above.  Lowering the limit so that 1M rays
+// take Onesweep was measured, same box: 0.170 ms at 1M rays, and 0.137 against 0.057 ms for a 131 072-ray shard -- Onesweep's
+// fixed cost is larger than the merge passes'.  The default stays.)
 static size_t radix_temp_bytes(size_t n) {
   size_t t64 = 0, t32 = 0;          // both key widths share the buffers: the larger temporary storage
   hipError_t e = rocprim::radix_sort_pairs(nullptr, t64, (const uint64_t*)nullptr, (uint64_t*)nullptr,

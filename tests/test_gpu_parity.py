@@ -957,3 +957,63 @@ def test_call_sequence_is_graph_capturable(gpu, drrt_mod):
         assert cases.rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) <= 2e-6
     finally:
         drrt_mod.options.check_failed = True
+
+
+@pytest.mark.parametrize("blocks,extra", [(1, 0), (7, 13), (8, 0), (9, 1), (127, 255), (128, 0), (129, 77), (263, 5)])
+def test_xcd_block_order_visits_every_ray_once(gpu, drrt_mod, blocks, extra):
+    """xcd_block (csrc/drrt_kernels.hip) hands the launch's blocks the visit order XCD by XCD -- runs of 16 per XCD in the
+    forward march, one run per XCD in the ring-window adjoint.  A remap that is not a bijection for some block count would
+    leave rays unmarched or march them twice: block counts around the multiples of 8 and of 128 (the group size of the
+    forward's remap), with a ragged last block.  Forward: bit-identical to DRRT_FLAG_DISPATCH_IN_ORDER and to the unsorted
+    call; adjoint (ring kernel forced, with both hints): same step total and the same gradient up to summation order."""
+    import ctypes as C
+    from adjointnonlinearraytracing_amd import _lib
+    lib = _lib.load()
+    R = 17; span = 1.0; h = span / (R - 1); ds = h / 2
+    rif_np = cases.luneburg(R)
+    n_want = (blocks - 1) * 256 + (extra if extra else 256)
+    pos, vel = cases.cube_rays(n_want // 6 + 1, span, ds, seed=blocks, tilt=0.2)
+    pos, vel = pos[:n_want], vel[:n_want]
+    n = pos.shape[0]
+    assert n == n_want and (n + 255) // 256 == blocks
+    rif = _t(rif_np, gpu).reshape(-1).contiguous()
+    res = (C.c_int * 3)(R, R, R)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    xs, vs = _t(pos, gpu), _t(vel, gpu)
+    outs = {}
+    for name, flags in (("unsorted", 0), ("in_order", 1 | _lib.FLAG_DISPATCH_IN_ORDER), ("xcd", 1)):
+        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, rif.numel(), flags)) + 1024, dtype=torch.uint8, device=gpu)
+        xt = torch.full((n, 3), float("nan"), device=gpu); vt = torch.full((n, 3), float("nan"), device=gpu)
+        st = torch.zeros(3, dtype=torch.int64, device=gpu)
+        _lib.check(lib.drrt_trace_f32(p(rif), rif.numel(), res, n, p(xs), p(vs), h, ds, p(xt), p(vt), p(st), p(ws), ws.numel(), flags, None))
+        torch.cuda.synchronize()
+        outs[name] = (xt.cpu().numpy(), vt.cpu().numpy(), int(st[0]))
+        if name == "xcd":
+            cnt = C.c_size_t(0)
+            order = torch.empty(n, dtype=torch.int32, device=gpu)
+            ptr = lib.drrt_last_order(C.byref(cnt))
+            assert ptr and cnt.value == n
+            off = ptr - ws.data_ptr()
+            order.copy_(ws[off:off + 4 * n].view(torch.int32))
+            ptr_s = lib.drrt_last_steps(C.byref(cnt))
+            assert ptr_s and cnt.value == n
+            off = ptr_s - ws.data_ptr()
+            fsteps = ws[off:off + 4 * n].view(torch.int32).clone()
+    for name in ("in_order", "xcd"):
+        assert not np.isnan(outs[name][0]).any()
+        assert np.array_equal(outs[name][0], outs["unsorted"][0]) and np.array_equal(outs[name][1], outs["unsorted"][1]), name
+        assert outs[name][2] == outs["unsorted"][2], name
+    xt, vt = _t(outs["xcd"][0], gpu), _t(outs["xcd"][1], gpu)
+    dx, dv = torch.ones_like(xt), torch.ones_like(vt)
+    grads = {}
+    for name, flags in (("in_order", 1 | _lib.FLAG_RING_WINDOW | _lib.FLAG_DISPATCH_IN_ORDER), ("xcd", 1 | _lib.FLAG_RING_WINDOW)):
+        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, rif.numel(), flags)) + 1024, dtype=torch.uint8, device=gpu)
+        g = torch.empty_like(rif)
+        st = torch.zeros(3, dtype=torch.int64, device=gpu)
+        lib.drrt_set_order_hint(p(order), n)
+        lib.drrt_set_step_hint(p(fsteps), n)
+        _lib.check(lib.drrt_backtrace_f32(p(rif), rif.numel(), res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(g), p(st), p(ws), ws.numel(), flags, None))
+        torch.cuda.synchronize()
+        grads[name] = (g.cpu().numpy(), int(st[0]))
+    assert grads["xcd"][1] == grads["in_order"][1]
+    assert cases.rel_l2(grads["xcd"][0], grads["in_order"][0]) <= 2e-5
