@@ -66,12 +66,18 @@ __device__ __forceinline__ bool ray_index(const uint32_t* __restrict__ perm, siz
 // order are neighbours in space -- their bundles read overlapping cells of the grid -- so an XCD takes CONSECUTIVE blocks
 // of the visit order instead of every 8th one: a border cell is then fetched into one L2, not eight.  Bijective for every
 // block count; a pure speed choice (a different placement is slower, not wrong).  Measured on MI355X, same box, 256^3 /
-// 1M rays (gpurun_out/xcd, xcd2), identity / runs of 16 / runs of 64 / one run per XCD:
-//   forward march (metric)           1.043 / 0.99-1.01 / 1.004 / 1.05-1.065 ms
-//   box-window adjoint (metric)      4.66 / 4.68-4.78 / 4.71-4.73 / 4.68-4.73 ms
-//   ring-window adjoint (six views)  8.99-9.09 / 8.74-9.01 / 9.11-9.35 / 8.62-8.84 ms
-// so each kernel takes the order it measured best with: kXcdRuns16 (forward), kXcdOff (box adjoint), kXcdWhole (ring).
+// 1M rays (gpurun_out/xcd, xcd2, r3final), identity / runs of 16 / runs of 64 / one run per XCD:
+//   forward march (metric)                    1.043 / 0.99-1.01 / 1.004 / 1.05-1.065 ms
+//   box-window adjoint (metric)               4.66 / 4.68-4.78 / 4.71-4.73 / 4.68-4.73 ms
+//   ring-window adjoint, six rotated views    8.92-9.09 / 8.74-8.85 / 9.11-9.35 / 8.62-8.84 ms
+//   ring-window adjoint, 4 tomography views   5.30-5.32 / 5.23-5.25 / -- / 5.89-5.90 ms
+// One run per XCD hands whole VIEWS to single XCDs -- views differ in length and cost, and the launch then waits for the
+// XCD that drew the oblique ones -- so it is not used.  Runs of 16 for the forward march and the ring adjoint, blockIdx
+// order for the box adjoint (not bound by its gathers).
 enum { kXcdOff = 0, kXcdWhole = 1, kXcdRuns16 = 2 };
+#ifndef DRRT_RING_XCD_MODE
+#define DRRT_RING_XCD_MODE kXcdRuns16
+#endif
 __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb, int mode) {
   if (mode == kXcdRuns16) {            // groups of 8 * 16 consecutive blocks of the visit order: 16 for each XCD
     constexpr unsigned C = 16u, G = 8u * C;
@@ -1794,7 +1800,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
   wave_lds_fence();
 
   const Vol& V = a.vol;
-  const size_t t = (size_t)xcd_block(blockIdx.x, gridDim.x, a.xcd_order ? kXcdWhole : kXcdOff) * kBlock + threadIdx.x;
+  const size_t t = (size_t)xcd_block(blockIdx.x, gridDim.x, a.xcd_order ? DRRT_RING_XCD_MODE : kXcdOff) * kBlock + threadIdx.x;
   AdjState s;
   s.x = s.y = s.z = s.vx = s.vy = s.vz = s.lx = s.ly = s.lz = s.mx = s.my = s.mz = 0.f;
   s.active = false; s.outside = false;

@@ -962,9 +962,9 @@ def test_call_sequence_is_graph_capturable(gpu, drrt_mod):
 @pytest.mark.parametrize("blocks,extra", [(1, 0), (7, 13), (8, 0), (9, 1), (127, 255), (128, 0), (129, 77), (263, 5)])
 def test_xcd_block_order_visits_every_ray_once(gpu, drrt_mod, blocks, extra):
     """xcd_block (csrc/drrt_kernels.hip) hands the launch's blocks the visit order XCD by XCD -- runs of 16 per XCD in the
-    forward march, one run per XCD in the ring-window adjoint.  A remap that is not a bijection for some block count would
-    leave rays unmarched or march them twice: block counts around the multiples of 8 and of 128 (the group size of the
-    forward's remap), with a ragged last block.  Forward: bit-identical to DRRT_FLAG_DISPATCH_IN_ORDER and to the unsorted
+    forward march and in the ring-window adjoint.  A remap that is not a bijection for some block count would leave rays
+    unmarched or march them twice: block counts around the multiples of 8 and of 128 (the remap's group size), with a
+    ragged last block.  Forward: bit-identical to DRRT_FLAG_DISPATCH_IN_ORDER and to the unsorted
     call; adjoint (ring kernel forced, with both hints): same step total and the same gradient up to summation order."""
     import ctypes as C
     from adjointnonlinearraytracing_amd import _lib
