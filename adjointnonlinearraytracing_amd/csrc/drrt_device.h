@@ -441,9 +441,10 @@ struct AdjSample { float n, gx, gy, gz, hxy, hxz, hyz; };   // n, grad n (scaled
 
 // First half (src/tracer.cpp:421-425; sdf :488-497): sample the cell `c` the ray has just stepped into (taps `t`),
 // update v, decide whether the ray is still active.  Everything on the march's critical path is here.
+// MODE 1: `st` are the 8 sdf taps of the cell when the caller has gathered them ahead (`have_st`), else they are fetched here.
 template <int MODE>   // 0 = backtrace, 1 = backtrace_sdf
-DRRT_HD bool adj_sample(const Vol& V, const float* __restrict__ sdf, float ds, AdjState& s, const Cell& c, const Taps& t,
-                        AdjSample& m) {
+DRRT_HD bool adj_sample_st(const Vol& V, const float* __restrict__ sdf, float ds, AdjState& s, const Cell& c, const Taps& t,
+                           AdjSample& m, const Taps& st, bool have_st) {
   const Sample q = interp<true>(t, c.wx, c.wy, c.wz);                                  // :421-422
   m.n = q.n; m.gx = q.gx * V.inv_h; m.gy = q.gy * V.inv_h; m.gz = q.gz * V.inv_h;
   m.hxy = q.hxy; m.hxz = q.hxz; m.hyz = q.hyz;
@@ -452,12 +453,17 @@ DRRT_HD bool adj_sample(const Vol& V, const float* __restrict__ sdf, float ds, A
   bool active = true;
   if (!c.interior) active = !escaped(V, s.x, s.y, s.z, -s.vx, -s.vy, -s.vz);            // :425
   if (MODE == 1) {                                                                      // :488-497
-    bool now_out = interp<false>(fetch(sdf, c), c.wx, c.wy, c.wz).n >= 0.f;
+    bool now_out = interp<false>(have_st ? st : fetch(sdf, c), c.wx, c.wy, c.wz).n >= 0.f;
     active = active & !((!s.outside) & now_out);
     s.outside = now_out;
   }
   s.active = active;
   return active;
+}
+template <int MODE>
+DRRT_HD bool adj_sample(const Vol& V, const float* __restrict__ sdf, float ds, AdjState& s, const Cell& c, const Taps& t,
+                        AdjSample& m) {
+  return adj_sample_st<MODE>(V, sdf, ds, s, c, t, m, t, false);
 }
 
 // Second half (:430-435), for a ray that is still active: its contribution `w` to dL/dn at the 8 taps of `c`, then

@@ -1228,9 +1228,26 @@ __device__ __forceinline__ bool flat_emit8(win_t* win, int wsy, int wsz, float* 
 }
 
 // How do the 64-ray bundles of this call sit at the start of the adjoint march?  One wave per bundle (the rays of 64
-// consecutive visit slots): bounding box of the rays' start cells -> [0] += 1 when the default box window cannot hold it,
-// [1] += 1 for every bundle looked at.  k_backtrace_flat and k_backtrace_ring read the two counters: one of them runs.
+// consecutive visit slots), every 16th block of bundles:
+//   [0] += 1 when the bounding box of the rays' start cells does not fit the default box window, [1] += 1 per bundle;
+//   [2] += the lanes whose start cell lies more than kClassifyReach cells (on any axis) from the bundle's mean cell,
+//          [3] += the lanes (diagnostic only: it does NOT predict which kernel is faster, see below).
+// k_backtrace_flat and k_backtrace_ring read the counters (bundles_want_ring): one of them runs.
+// Calibration (tools/probe_classify.py, 256^3, 1M rays unless noted; share of bundles not fitting -> box / ring kernel ms):
+//   metric 4 % -> 4.6 / 6.3; shifted plane 5 % -> 4.7 / 6.4; one view at 0 / 20 / 45 degrees through a weak lens 0 / 13 / 2 %
+//   -> 3.6 / 4.5, 4.3 / 5.8, 4.1 / 5.7; the same views through the Luneburg ball 4 / 14 / 11 % -> 4.6 / 6.3, 8.2 / 7.1,
+//   8.2 / 7.9; 527k rays ending on a sphere inside the lens, sorted by the adjoint itself 14 % -> 2.9 / 4.2; four sparse
+//   tomography views 45 % -> 8.9 / 5.3; six rotated views 28 % -> 21.3 / 8.9 (38 % -> 25.2 / 18.5 when the adjoint sorts).
+// Between 11 and 14 % the two kernels trade places by -34 ... +14 %; from 28 % on the ring kernel wins by 1.4-2.4x.  The
+// threshold is a fifth of the bundles (rounds 2-3: an eighth, which sent the 13-14 % cases to the ring kernel: -34 / -42 %).
 constexpr unsigned kClassifyStride = 16;     // every 16th block of bundles is looked at (contended atomics are the cost)
+constexpr int kClassifyReach = 3;            // 9 slots = 8 cells: the mean cell +- 3 and the upper taps, one cell to spare
+#ifndef DRRT_RING_MIN_NOFIT_PCT
+#define DRRT_RING_MIN_NOFIT_PCT 20
+#endif
+__device__ __forceinline__ bool bundles_want_ring(const unsigned* __restrict__ sel) {
+  return sel[0] * 100u >= sel[1] * (unsigned)DRRT_RING_MIN_NOFIT_PCT && sel[0] != 0u;
+}
 __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
   const Vol& V = a.vol;
   const size_t t = (size_t)blockIdx.x * kClassifyStride * kBlock + threadIdx.x;
@@ -1247,11 +1264,22 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
   const int x0 = wave_min_i32(ok ? cx : big), x1 = wave_max_i32(ok ? cx : -big);
   const int y0 = wave_min_i32(ok ? cy : big), y1 = wave_max_i32(ok ? cy : -big);
   const int z0 = wave_min_i32(ok ? cz : big), z1 = wave_max_i32(ok ? cz : -big);
-  if (lane == 0 && x1 >= x0) {
+  const unsigned lanes = (unsigned)__popcll(__ballot(ok));
+  if (lanes == 0u) return;                                                   // (wave-uniform)
+  // mean cell of the bundle (rounded); cells are < 2^24 per axis, 64 of them fit an int
+  const float inv = 1.0f / (float)lanes;
+  const int mx = (int)floorf((float)(int)wave_sum_u32(ok ? (unsigned)cx : 0u) * inv + 0.5f);
+  const int my = (int)floorf((float)(int)wave_sum_u32(ok ? (unsigned)cy : 0u) * inv + 0.5f);
+  const int mz = (int)floorf((float)(int)wave_sum_u32(ok ? (unsigned)cz : 0u) * inv + 0.5f);
+  const bool far = ok && (abs(cx - mx) > kClassifyReach || abs(cy - my) > kClassifyReach || abs(cz - mz) > kClassifyReach);
+  const unsigned outside = (unsigned)__popcll(__ballot(far));
+  if (lane == 0) {
     const int ex = x1 - x0 + 2, ey = y1 - y0 + 2, ez = z1 - z0 + 2;           // slots per axis
     const bool dflt = (ex <= kWinX - 2) & (ey <= kWinY - 2) & (ez <= kWinZ - 2);   // two slots of room for the placement
     if (!dflt) atomicAdd(&a.select[0], 1u);
     atomicAdd(&a.select[1], 1u);
+    if (outside) atomicAdd(&a.select[2], outside);
+    atomicAdd(&a.select[3], lanes);
   }
 }
 
@@ -1274,7 +1302,7 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
 template <bool ABL, bool PAIR, bool DYN, int MODE = 0>
 __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackArgs a) {
   if (a.select != nullptr) {
-    const bool want_dyn = a.select[0] * 8u >= a.select[1] && a.select[0] != 0u;     // >= 1/8 of the waves would gain
+    const bool want_dyn = bundles_want_ring(a.select);
     if (want_dyn != DYN) return;
   }
   constexpr int kSlots = DYN ? kWinCap : kWinFloats;
@@ -1312,6 +1340,8 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
   int lidx = -1;
   f4 q0 = f4{0.f, 0.f, 0.f, 0.f}, q1 = q0;                   // the taps, as gathered (gather_rows)
   int tbase = -1;                                            // cell whose taps the lane holds (-1: none)
+  Taps st;                                                   // MODE 1: the sdf taps of that cell, gathered with them
+  st.a = st.b = st.e = st.f = f2{0.f, 0.f};
   f2 p00 = f2{0.f, 0.f}, p10 = p00, p01 = p00, p11 = p00;   // accumulators of the cell: x-pairs at (y0,z0) (y1,z0) (y0,z1) (y1,z1)
   bool miss = false;                                         // the cell just entered lies outside the window
   const TapRows R = tap_rows<PAIR>(V);                       // wave-uniform row pointers + ONE 32-bit byte offset per lane
@@ -1329,6 +1359,10 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
       if (nbase != tbase) {
         __builtin_assume(nbase >= 0 && nbase < (1 << 29));
         gather_rows<PAIR>(R, tap_offset<PAIR>(nbase), q0, q1);
+        if (MODE == 1) {                                   // the sdf taps of the same cell ride along (src/tracer.cpp:488-497 reads them every step)
+          const float* sp = a.sdf + (unsigned)nbase;
+          st.a = ld_pair(sp); st.b = ld_pair(sp + V.sy); st.e = ld_pair(sp + V.sz); st.f = ld_pair(sp + V.sz + V.sy);
+        }
         tbase = nbase;
       }
     } else {
@@ -1445,13 +1479,10 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
         Cell c;                                              // what adj_sample reads of the cell: fractions, interior
         c.base = 0; c.ix = c.iy = c.iz = 0; c.ox = c.oy = c.oz = 0;
         c.wx = wx; c.wy = wy; c.wz = wz; c.interior = interior;
-        if (MODE == 1) {                                     // adj_sample<1> gathers the sdf taps of this cell itself
-          if (interior) { c.base = base; c.ox = 1; c.oy = V.sy; c.oz = V.sz; }
-          else c = locate(V, s.x, s.y, s.z);
-        }
+        if (MODE == 1 && !interior) c = locate(V, s.x, s.y, s.z);   // boundary cell: adj_sample<1> gathers its sdf taps itself
         const float px = s.x, py = s.y, pz = s.z;            // position of this sample (the clamped splat re-locates it)
         AdjSample m;
-        if (!adj_sample<MODE>(V, a.sdf, a.ds, s, c, taps_of<PAIR>(q0, q1), m)) {
+        if (!adj_sample_st<MODE>(V, a.sdf, a.ds, s, c, taps_of<PAIR>(q0, q1), m, st, MODE == 1 && interior)) {
           // the ray has ended (:426-428): it contributes nothing here; hand over what its cell has accumulated
           if (regular && experiment != 1) used_lds = flat_emit8<true>(win, WSY, WSZ, a.grad, V.sy, V.sz, lidx, base, p00, p10, p01, p11);
         } else {
@@ -1790,7 +1821,7 @@ __device__ __forceinline__ bool ring_cross(win_t* win, int experiment, bool pre,
 template <bool ABL, bool PAIR, int MODE = 0>
 __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(BackArgs a) {
   if (a.select != nullptr) {                                 // launched next to k_backtrace_flat<.., DYN = false>: the bundle
-    const bool want_fit = a.select[0] * 8u >= a.select[1] && a.select[0] != 0u;     // classification picks one of the two
+    const bool want_fit = bundles_want_ring(a.select);                                // classification picks one of the two
     if (!want_fit) return;
   }
   __shared__ win_t s_win[kWavesPerBlock][kRingCap];
@@ -2390,6 +2421,8 @@ extern "C" const uint32_t* drrt_last_steps(size_t* n_out) {
   return g_last_steps;
 }
 extern "C" void drrt_set_step_hint(const uint32_t* steps, size_t n) { g_hint_steps = steps; g_hint_steps_n = steps ? n : 0; }
+static thread_local const unsigned* g_last_counters = nullptr;   // bundle classification of the last adjoint call (device, in its workspace)
+extern "C" const unsigned* drrt_last_bundle_counters(void) { return g_last_counters; }
 
 // ---- optional per-kernel timing (bench / profiling aid; not thread-safe) --------------------
 // Event pairs are recorded on the call's stream right around a kernel launch; nothing
@@ -2814,11 +2847,13 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
       // of a drrt_workspace_bytes_grid() workspace; without it, or without an order, the box-window kernel runs.
       // DRRT_FLAG_STATIC_WINDOW / DRRT_FLAG_RING_WINDOW force one of the two (A-B).
       a.select = nullptr;
+      g_last_counters = nullptr;
       const size_t ctr_off = (drrt_workspace_bytes(n, flags) + ((flags & DRRT_FLAG_PAIR_GRID) ? (size_t)nvox * 2 * sizeof(float) : 0) + 7) & ~(size_t)7;
       const bool force_box = (flags & DRRT_FLAG_STATIC_WINDOW) != 0 || a.experiment == 7, force_ring = (flags & DRRT_FLAG_RING_WINDOW) != 0;
       if (!force_box && !force_ring && a.perm != nullptr && ws && ws_bytes >= ctr_off + 512) {
         a.select = (unsigned*)((char*)ws + ctr_off + 256);
-        hipError_t e = hipMemsetAsync(a.select, 0, 8, s);
+        g_last_counters = a.select;
+        hipError_t e = hipMemsetAsync(a.select, 0, 16, s);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(select)");
         hipLaunchKernelGGL(k_bundle_classify, dim3((g.x + kClassifyStride - 1) / kClassifyStride), dim3(kBlock), 0, s, a);
       }

@@ -282,6 +282,32 @@ def _capture_order(n: int, device: torch.device) -> None:
             last_order.drrt_steps = ws[off_s:off_s + 4 * n].view(torch.int32).clone()
 
 
+last_bundle_counters: Optional[torch.Tensor] = None
+
+
+def _capture_counters(ws: torch.Tensor) -> None:
+    """The bundle classification of the adjoint call just made (drrt_last_bundle_counters, include/drrt_hip.h): four int32
+    copied out of its workspace (device-to-device, async) -> `last_bundle_counters`, or None when the call did not classify."""
+    global last_bundle_counters
+    last_bundle_counters = None
+    ptr = _lib.load().drrt_last_bundle_counters()
+    if not ptr:
+        return
+    off = int(ptr) - ws.data_ptr()
+    if 0 <= off and off + 16 <= ws.numel():
+        last_bundle_counters = ws[off:off + 16].view(torch.int32).clone()
+
+
+def read_bundle_counters() -> Optional[Dict[str, int]]:
+    """Synchronising read of `last_bundle_counters` -> which adjoint kernel the last backtrace* call chose, and why."""
+    if last_bundle_counters is None:
+        return None
+    c = [int(v) for v in last_bundle_counters.cpu()]
+    share = c[0] / c[1] if c[1] else 0.0
+    return dict(bundles_not_fitting=c[0], bundles=c[1], lanes_outside=c[2], lanes=c[3], not_fitting_share=share,
+                kernel="ring" if (c[0] and c[0] * 100 >= c[1] * 20) else "box")
+
+
 def _hint(order: Optional[torch.Tensor], n: int) -> None:
     if order is not None and order.numel() == n and order.dtype == torch.int32 and order.is_cuda:
         _lib.load().drrt_set_order_hint(C.c_void_p(order.data_ptr()), n)
@@ -485,6 +511,7 @@ class TracerC:
                 _lib.check(fn(
                     _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
                     float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+                _capture_counters(ws)
             finally:
                 _clear_hint()
         return grad
@@ -507,6 +534,7 @@ class TracerC:
                 _lib.check(_lib.load().drrt_backtrace_sdf_f32(
                     _p(rif_), _p(sdf_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
                     float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
+                _capture_counters(ws)
             finally:
                 _clear_hint()
         return grad

@@ -180,6 +180,15 @@ DRRT_API size_t drrt_order_hint_pending(void);
 DRRT_API const uint32_t* drrt_last_steps(size_t* n_out);
 DRRT_API void drrt_set_step_hint(const uint32_t* steps, size_t n);
 
+/* Which adjoint kernel ran, and why: a DEVICE pointer to the four counters of the bundle classification of the last
+ * drrt_backtrace_* / drrt_backtrace_sdf_f32 call on this host thread that classified its bundles (it lies in that call's
+ * workspace: valid while the workspace is, read it after synchronising the stream), or NULL when that call did not (no visit
+ * order, a forced kernel, a workspace without the counter block).  Over every 16th block of 64-ray bundles:
+ *   [0] bundles whose start cells do not fit the box window, [1] bundles looked at,
+ *   [2] lanes whose start cell lies more than 3 cells from their bundle's mean cell, [3] lanes looked at (diagnostic).
+ * The ring-window kernel runs when [0] / [1] >= 20 % (calibration: csrc/drrt_kernels.hip, k_bundle_classify). */
+DRRT_API const unsigned* drrt_last_bundle_counters(void);
+
 /* ---- 16-bit ray state "q16" (BASELINE.json config 5: "fp16 ray state + fp32 adjoint accumulate") -----------------
  * The reference is fp32-only (include/types.h:36-46).  IEEE half keeps 11 significant bits wherever the value is:
  * a position near 1.0 is rounded to 2^-11 = 1/8 voxel of a 256^3 grid, which changes the adjoint trajectories

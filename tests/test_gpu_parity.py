@@ -1017,3 +1017,29 @@ def test_xcd_block_order_visits_every_ray_once(gpu, drrt_mod, blocks, extra):
         grads[name] = (g.cpu().numpy(), int(st[0]))
     assert grads["xcd"][1] == grads["in_order"][1]
     assert cases.rel_l2(grads["xcd"][0], grads["in_order"][0]) <= 2e-5
+
+
+def test_bundle_classification_counters(gpu, drrt_mod):
+    """drrt_last_bundle_counters (include/drrt_hip.h): the adjoint's device-side choice between the box-window and the
+    ring-window kernel is readable after the call.  Rays of an axis-aligned plane view on a 65^3 grid form compact
+    bundles (box kernel); forcing a kernel skips the classification (no counters); the gradient does not depend on it."""
+    R = 65; span = 1.0; h = span / (R - 1); ds = h / 2
+    rif = _t(cases.luneburg(R), gpu)
+    pos, vel = cases.plane_rays(40000, span, ds, seed=4, axis=1, tilt=0.0)
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = True
+    xt, vt = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+    order = drrt_mod.last_order
+    n = xt.shape[0]
+    ones = torch.ones_like(xt)
+    g_auto = T.backtrace(rif, rif.shape, xt, vt, ones, ones, h, ds, order=order)
+    c = drrt_mod.read_bundle_counters()
+    assert c is not None
+    blocks = (n + 255) // 256
+    assert 0 < c["bundles"] <= 4 * ((blocks + 15) // 16)
+    assert 0 < c["lanes"] <= 64 * c["bundles"] and c["lanes_outside"] <= c["lanes"] and c["bundles_not_fitting"] <= c["bundles"]
+    assert c["kernel"] == "box" and c["not_fitting_share"] < 0.2
+    with drrt_mod.using(adjoint_window="ring"):
+        g_ring = T.backtrace(rif, rif.shape, xt, vt, ones, ones, h, ds, order=order)
+        assert drrt_mod.read_bundle_counters() is None
+    assert cases.rel_l2(g_ring.cpu().numpy(), g_auto.cpu().numpy()) <= 2e-5
