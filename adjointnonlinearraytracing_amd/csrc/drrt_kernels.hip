@@ -707,11 +707,10 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_direct(BackArgs a) {
 // boundary cell) fall back to direct global atomics, so the result never depends on the window.
 //
 //   window      kWinX x kWinY x kWinZ voxels of double accumulators, row pitch kWinPX (measured, final
-//               kernels: edge 9 beats 7, 8, 10, 12; padding the pitch or not is within 1 %); the flat
-//               kernel can also size the window to the wave's rays at run time (WinDyn)
+//               kernels: edge 9 beats 7, 8, 10, 12; padding the pitch or not is within 1 %)
 //   ablations   BackArgs::experiment (bits 8..15 of `flags`, development only): 1 = no accumulation
 //               at all, 2 = no global atomics, 3 = no LDS adds, 4 = hand over all 8 corners on every
-//               leave, 5 = never flush, 6 = no DPP pre-reduction, 7 = never fit the window
+//               leave, 5 = never flush, 6 = no DPP pre-reduction, 7 = the box-window kernel, nothing ablated
 //   anchor      around the cell of the wave's median contributing lane, shifted towards its
 //               direction of travel (most of the window lies ahead of the rays)
 //   re-anchor   as soon as a contributing lane misses the window (wave-uniform decision); if lanes
@@ -1113,28 +1112,9 @@ __global__ void __launch_bounds__(kBlock) k_backtrace_win(BackArgs a) {
 // 5.41-5.50 ms for k_backtrace_win<0> with the pipelined loop and 5.45 ms without); backtrace_sdf, the quad-grid option
 // and DRRT_FLAG_LEGACY_ADJOINT keep k_backtrace_win.
 // ---------------------------------------------------------------------------------------------
-// ---- window of k_backtrace_flat: dimensions chosen when it is anchored -------------------------------------------
-// A wave's 64 rays usually fit the default 9^3 window, but not always: the locality sort forms Z-order tiles whose
-// aspect can reach 2:1, and the rays of a view that is oblique to the grid start the adjoint on an oblique exit face,
-// i.e. staggered along their direction (measured: a 45-degree plane view with 4 rays per voxel column had 27 % of its
-// ray-steps outside a 9^3 window and ran 4x slower per ray-step than the axis-aligned view).  So when lanes still miss
-// the default window right after it was re-anchored, the wave switches to windows fitted to the bounding box of its
-// rays' cells, within the same LDS capacity.  Everything here is wave-uniform (SGPRs).
-constexpr int kWinCap = 1000;      // slots per wave (8000 B): 5 blocks of 4 waves per CU, what the VGPR count allows anyway
-struct WinDyn {
-  int ox, oy, oz;                  // corner 000 of the window, in voxels (far away = nothing is inside)
-  int dx, dy, dz;                  // slots per axis; a cell (lx, ly, lz) needs slots lx..lx+1 etc., so dim - 1 cells fit
-  int sy, sz;                      // LDS strides of y and z in slots: sy = dx + 1 (pad), sz = sy * dy
-  int rpp;                         // flush: rows per pass = 64 / dx
-  float inv_dx, inv_dy;            // flush: 1/dx, 1/dy (lane -> row, row -> (ly, lz))
-};
-__device__ __forceinline__ void win_set_dims(WinDyn& W, int dx, int dy, int dz) {
-  dx = __builtin_amdgcn_readfirstlane(dx); dy = __builtin_amdgcn_readfirstlane(dy); dz = __builtin_amdgcn_readfirstlane(dz);
-  W.dx = dx; W.dy = dy; W.dz = dz; W.sy = dx + 1; W.sz = (dx + 1) * dy;
-  W.rpp = __builtin_amdgcn_readfirstlane((int)(64.0f / (float)dx));
-  W.inv_dx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / (float)dx)));
-  W.inv_dy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / (float)dy)));
-}
+// ---- window of k_backtrace_flat --------------------------------------------------------------------------------
+// (Bundles that do not sit in the compile-time window -- sparse views, views oblique to the grid -- are the ring kernel's.)
+struct WinOrg { int ox, oy, oz; };   // corner 000 of the wave's window, in voxels (far away = nothing is inside); wave-uniform
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
@@ -1145,47 +1125,6 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
   return v;
 }
-__device__ __forceinline__ int win_index_dyn(const WinDyn& W, int cx, int cy, int cz) {
-  const int lx = cx - W.ox, ly = cy - W.oy, lz = cz - W.oz;
-  const bool in = ((unsigned)lx < (unsigned)(W.dx - 1)) & ((unsigned)ly < (unsigned)(W.dy - 1)) &
-                  ((unsigned)lz < (unsigned)(W.dz - 1));
-  // v_mad_u32_u24 by hand (lx, ly, lz are small and non-negative whenever the result is used)
-  int r;
-  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(ly), "s"(W.sy), "v"(lx));
-  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(lz), "s"(W.sz), "v"(r));
-  return in ? r : -1;
-}
-// Flush the window into the grid and leave it zeroed (all 64 lanes).  Rows (the dx slots of one (ly, lz)) are contiguous
-// in LDS at pitch sy, so the flush walks them linearly, rpp = 64 / dx rows per pass (lane -> row lane / dx, slot
-// lane % dx), four passes per batch: four LDS exchanges are in flight before the first result is used.
-__device__ __forceinline__ void win_flush_dyn(win_t* win, const WinDyn& W, float* __restrict__ grad, const Vol& V,
-                                              int lane, bool no_global) {
-  wave_lds_fence();
-  const int rows = W.dy * W.dz;
-  const int rsub = (int)(((float)lane + 0.5f) * W.inv_dx), lx = lane - rsub * W.dx;
-  const bool lane_ok = rsub < W.rpp;
-  const unsigned g0 = (unsigned)W.oz * (unsigned)V.sz + (unsigned)W.oy * (unsigned)V.sy + (unsigned)(W.ox + lx);
-  constexpr int kBatch = 4;
-#pragma unroll 1
-  for (int r0 = 0; r0 < rows; r0 += kBatch * W.rpp) {
-    win_t v[kBatch];
-    unsigned g[kBatch];
-#pragma unroll
-    for (int b = 0; b < kBatch; ++b) {
-      const int r = r0 + b * W.rpp + rsub;                                   // row index = lz * dy + ly
-      const int lz = (int)(((float)r + 0.5f) * W.inv_dy), ly = r - lz * W.dy;
-      v[b] = (win_t)0;
-      g[b] = g0 + (unsigned)lz * (unsigned)V.sz + (unsigned)ly * (unsigned)V.sy;
-      // ds_wrxchg_rtn_b64: read the accumulated value and reset the slot in one LDS op
-      if (lane_ok & (r < rows)) v[b] = __hip_atomic_exchange(win + r * W.sy + lx, (win_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-#pragma unroll
-    for (int b = 0; b < kBatch; ++b)
-      if (v[b] != (win_t)0 && !no_global) atomic_add_f32(grad + g[b], (float)v[b]);
-  }
-  wave_lds_fence();
-}
-
 __device__ __forceinline__ int win_index(int wox, int woy, int woz, int cx, int cy, int cz) {
   const int lx = cx - wox, ly = cy - woy, lz = cz - woz;
   const bool in = ((unsigned)lx < (unsigned)(kWinX - 1)) & ((unsigned)ly < (unsigned)(kWinY - 1)) &
@@ -1292,20 +1231,16 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
                              // (4 -> 4.89 ms, 5 -> 4.85, 6 -> 5.19 on the final kernel)
 #endif
 // PAIR: gather from the pair copy of the grid (two 16-byte loads per cell, see gather_rows).
-// DYN : (round 2, no longer launched: k_backtrace_ring took its place) box windows with run-time dimensions, fitted to the
-//       wave's rays when the default kWin^3 window cannot hold them (WinDyn); DYN = false is the kernel with compile-time
-//       window strides.  When the call has a visit order the host launches this kernel AND k_backtrace_ring, and each
-//       returns at once unless a.select picks it (k_bundle_classify decides on the device, from how the 64-ray bundles
-//       sit at their start, without a host round trip).
+// When the call has a visit order the host launches this kernel AND k_backtrace_ring, and each returns at once unless
+// a.select picks it (k_bundle_classify decides on the device, from how the 64-ray bundles sit at their start, without a
+// host round trip).  (Round 2's run-time-sized box windows -- a DYN instantiation of this kernel -- were replaced by the
+// ring kernel in round 3 and are gone.)
 // MODE: 0 = backtrace, 1 = backtrace_sdf (the ray also ends where the sdf sample turns non-negative, :488-497; the sdf
-//       taps are a second, un-pipelined gather per step).
-template <bool ABL, bool PAIR, bool DYN, int MODE = 0>
+//       taps ride along with the grid's taps).
+template <bool ABL, bool PAIR, int MODE = 0>
 __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackArgs a) {
-  if (a.select != nullptr) {
-    const bool want_dyn = bundles_want_ring(a.select);
-    if (want_dyn != DYN) return;
-  }
-  constexpr int kSlots = DYN ? kWinCap : kWinFloats;
+  if (a.select != nullptr && bundles_want_ring(a.select)) return;
+  constexpr int kSlots = kWinFloats;
   __shared__ win_t s_win[kWavesPerBlock][kSlots];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   win_t* win = s_win[wid];
@@ -1328,8 +1263,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
     }
   }
   const int experiment = ABL ? a.experiment : 0;
-  WinDyn W;                                                    // the wave's window (wave-uniform)
-  win_set_dims(W, kWinX, kWinY, kWinZ);
+  WinOrg W;                                                    // the wave's window (wave-uniform)
   W.ox = W.oy = W.oz = -(1 << 28);                             // far away = nothing is inside
   // the cell the ray stands on, located IN PLACE: flat index and coordinates of corner 000, in-cell fractions, strictly
   // interior / regular (no clamped neighbour), window slot.  A boundary cell's clamp offsets are not carried: the
@@ -1387,9 +1321,9 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
   // the window), [7] leaves that handed over all eight corners, [8] wave-steps, [9] wave-steps with leaves across >= 2 axes
   unsigned ev_face = 0, ev_add = 0, ev_glob = 0, ev_all8 = 0, ev_wsteps = 0, ev_multi = 0;
 
-#define WSY (DYN ? W.sy : kWinSY)
-#define WSZ (DYN ? W.sz : kWinSZ)
-#define WIN_INDEX(cx, cy, cz) (DYN ? win_index_dyn(W, cx, cy, cz) : win_index(W.ox, W.oy, W.oz, cx, cy, cz))
+#define WSY kWinSY
+#define WSZ kWinSZ
+#define WIN_INDEX(cx, cy, cz) win_index(W.ox, W.oy, W.oz, cx, cy, cz)
     for (int it = 0; it < a.max_steps; ++it) {
       if (!__any(s.active)) break;                                              // wave-uniform exit
 #if defined(DRRT_PAD_VALU)
@@ -1411,8 +1345,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
       const unsigned long long mm = __ballot(s.active & miss);
       if (mm != 0ull && cooldown == 0) {
         if (dirty) {
-          if constexpr (DYN) win_flush_dyn(win, W, a.grad, V, lane, experiment == 2);
-          else win_flush(win, W.ox, W.oy, W.oz, a.grad, V, lane, experiment == 2);
+          win_flush(win, W.ox, W.oy, W.oz, a.grad, V, lane, experiment == 2);
           dirty = false; ++n_flush;
         }
         const bool ok = s.active & regular;
@@ -1426,7 +1359,6 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
         const float inv_dm = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(dx_), fabsf(dy_)), fmaxf(fabsf(dz_), 1e-30f)));   // placement only
         {
           // default: a kWin^3 window around the median lane's cell, shifted towards the direction of travel
-          if constexpr (DYN) { if (W.dx != kWinX || W.dy != kWinY || W.dz != kWinZ) win_set_dims(W, kWinX, kWinY, kWinZ); }
           const float fx = 0.5f - DRRT_ANCHOR_SHIFT * (dx_ * inv_dm), fy = 0.5f - DRRT_ANCHOR_SHIFT * (dy_ * inv_dm), fz = 0.5f - DRRT_ANCHOR_SHIFT * (dz_ * inv_dm);
           int ox = rx - (int)(fx * (float)(kWinX - 2));
           int oy = ry - (int)(fy * (float)(kWinY - 2));
@@ -1436,38 +1368,6 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
           W.oz = __builtin_amdgcn_readfirstlane(oz);
           lidx = regular ? WIN_INDEX(ix, iy, iz) : -1;                          // every lane's cell, in the new window
           miss = ok & (lidx < 0);
-        }
-        if (DYN && __ballot(miss) != 0ull) {
-          // The default window cannot hold this wave.  Would a window fitted to the bounding box of its rays' cells?
-          const int big = 1 << 28;
-          const int x0 = wave_min_i32(ok ? ix : big), x1 = wave_max_i32(ok ? ix : -big);
-          const int y0 = wave_min_i32(ok ? iy : big), y1 = wave_max_i32(ok ? iy : -big);
-          const int z0 = wave_min_i32(ok ? iz : big), z1 = wave_max_i32(ok ? iz : -big);
-          const int ex = x1 - x0 + 2, ey = y1 - y0 + 2, ez = z1 - z0 + 2;       // slots the cells need per axis
-          const bool fits = __builtin_amdgcn_readfirstlane((int)((ex <= 16) & ((ex + 1) * ey * ez <= kWinCap))) != 0;
-          if (fits) {
-            if constexpr (DYN) {
-              // room ahead of the rays: up to 3 slots along the direction of travel, as far as the capacity allows
-              int dx = min(ex + (int)(3.0f * fabsf(dx_) * inv_dm + 0.5f), 16);
-              int dy = ey + (int)(3.0f * fabsf(dy_) * inv_dm + 0.5f);
-              int dz = ez + (int)(3.0f * fabsf(dz_) * inv_dm + 0.5f);
-              dx = __builtin_amdgcn_readfirstlane(dx); dy = __builtin_amdgcn_readfirstlane(dy); dz = __builtin_amdgcn_readfirstlane(dz);
-  #pragma unroll 1
-              for (int guard = 0; guard < 16 && (dx + 1) * dy * dz > kWinCap; ++guard) {
-                if (dz > ez && dz - ez >= dy - ey && dz - ez >= dx - ex) --dz;      // give back the largest margin first
-                else if (dy > ey && dy - ey >= dx - ex) --dy;
-                else if (dx > ex) --dx;
-              }
-              win_set_dims(W, dx, dy, dz);
-              // origin: the box's low corner, moved back by the spare slots when the rays travel towards lower indices
-              int ox = dx_ < 0.f ? x0 - (dx - ex) : x0, oy = dy_ < 0.f ? y0 - (dy - ey) : y0, oz = dz_ < 0.f ? z0 - (dz - ez) : z0;
-              ox = max(0, min(ox, V.W - dx)); oy = max(0, min(oy, V.H - dy)); oz = max(0, min(oz, V.D - dz));
-              W.ox = __builtin_amdgcn_readfirstlane(ox); W.oy = __builtin_amdgcn_readfirstlane(oy);
-              W.oz = __builtin_amdgcn_readfirstlane(oz);
-              lidx = regular ? WIN_INDEX(ix, iy, iz) : -1;
-              miss = ok & (lidx < 0);
-            }
-          }
         }
         cooldown = (__ballot(miss) != 0ull) ? 4 : 0;                            // incoherent wave: do not thrash
       } else if (cooldown > 0) {
@@ -1617,13 +1517,11 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
 #undef WIN_INDEX
   dirty = __ballot(dirty) != 0ull;
   if (dirty) {
-    if constexpr (DYN) win_flush_dyn(win, W, a.grad, V, lane, experiment == 2);
-    else win_flush(win, W.ox, W.oy, W.oz, a.grad, V, lane, experiment == 2);
+    win_flush(win, W.ox, W.oy, W.oz, a.grad, V, lane, experiment == 2);
     ++n_flush;
   }
   if (ABL && a.dbg) {
     if (lane == 0) atomicAdd(&a.dbg[0], (unsigned long long)n_flush);
-    if (DYN && lane == 0) atomicAdd(&a.dbg[3], 1ull);          // waves that ran with run-time window dimensions
     if (ev_face) atomicAdd(&a.dbg[4], (unsigned long long)ev_face);
     if (ev_add) atomicAdd(&a.dbg[5], (unsigned long long)ev_add);
     if (ev_glob) atomicAdd(&a.dbg[6], (unsigned long long)ev_glob);
@@ -1820,7 +1718,7 @@ __device__ __forceinline__ bool ring_cross(win_t* win, int experiment, bool pre,
 
 template <bool ABL, bool PAIR, int MODE = 0>
 __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(BackArgs a) {
-  if (a.select != nullptr) {                                 // launched next to k_backtrace_flat<.., DYN = false>: the bundle
+  if (a.select != nullptr) {                                 // launched next to k_backtrace_flat: the bundle
     const bool want_fit = bundles_want_ring(a.select);                                // classification picks one of the two
     if (!want_fit) return;
   }
@@ -2859,11 +2757,11 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
       }
       if (!force_ring) {
         if (abl && MODE == 0) {
-          if (pair) hipLaunchKernelGGL((k_backtrace_flat<true, true, false, 0>), g, dim3(kBlock), 0, s, a);
-          else      hipLaunchKernelGGL((k_backtrace_flat<true, false, false, 0>), g, dim3(kBlock), 0, s, a);
+          if (pair) hipLaunchKernelGGL((k_backtrace_flat<true, true, 0>), g, dim3(kBlock), 0, s, a);
+          else      hipLaunchKernelGGL((k_backtrace_flat<true, false, 0>), g, dim3(kBlock), 0, s, a);
         } else {    /* the ablation / counter instantiation exists for backtrace only */
-          if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true, false, MODE>), g, dim3(kBlock), 0, s, a);
-          else      hipLaunchKernelGGL((k_backtrace_flat<false, false, false, MODE>), g, dim3(kBlock), 0, s, a);
+          if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true, MODE>), g, dim3(kBlock), 0, s, a);
+          else      hipLaunchKernelGGL((k_backtrace_flat<false, false, MODE>), g, dim3(kBlock), 0, s, a);
         }
       }
       if (force_ring || a.select != nullptr) {
