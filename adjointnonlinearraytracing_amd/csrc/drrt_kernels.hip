@@ -2700,6 +2700,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
                          float h, float ds, float* grad, drrt_stats* stats, void* ws, size_t ws_bytes,
                          unsigned flags, void* stream, int io_half = 0) {
   const OrderHint hint = take_hint();
+  g_last_counters = nullptr;              // set again below when this call classifies its bundles
   g_err[0] = 0;
   hipStream_t s = (hipStream_t)stream;
   BackArgs a{};
@@ -2745,7 +2746,6 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
       // of a drrt_workspace_bytes_grid() workspace; without it, or without an order, the box-window kernel runs.
       // DRRT_FLAG_STATIC_WINDOW / DRRT_FLAG_RING_WINDOW force one of the two (A-B).
       a.select = nullptr;
-      g_last_counters = nullptr;
       const size_t ctr_off = (drrt_workspace_bytes(n, flags) + ((flags & DRRT_FLAG_PAIR_GRID) ? (size_t)nvox * 2 * sizeof(float) : 0) + 7) & ~(size_t)7;
       const bool force_box = (flags & DRRT_FLAG_STATIC_WINDOW) != 0 || a.experiment == 7, force_ring = (flags & DRRT_FLAG_RING_WINDOW) != 0;
       if (!force_box && !force_ring && a.perm != nullptr && ws && ws_bytes >= ctr_off + 512) {
