@@ -97,6 +97,9 @@ def parse_args(argv=None):
     ap.add_argument("--workload", choices=("metric", "cube6_rotated", "plane_shifted"), default="metric",
                     help="ray set of the MAIN run (default: the metric's plane source).  The other two are the `variants` ray "
                          "sets run as the main workload -- for profiling them on their own (1 GPU)")
+    ap.add_argument("--source-axis", choices=("x", "y", "z"), default="y",
+                    help="A-B: the metric's plane source on the x=0 / z=0 face instead of y=0 (rays along that axis; the ball is "
+                         "symmetric, so the work is the same and only the memory order of the cells along the rays differs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
                                                         "to rehearse the multi-rank flow on a 1-GPU box)")
     args = ap.parse_args(argv)
@@ -532,6 +535,9 @@ def run_rank(args) -> int:
             return out
         if mode == "strong":
             gpos, gvel = make_rays(args.rays, seed=0)              # the metric's single ray set, same on every rank
+            if args.source_axis != "y":                            # A-B: the same source on another face (the ball is symmetric)
+                perm = {"x": [1, 0, 2], "z": [0, 2, 1]}[args.source_axis]
+                gpos, gvel = gpos[:, perm].contiguous(), gvel[:, perm].contiguous()
             lo, hi = drrt_dist.shard_bounds(args.rays, rank, world)
             if args.shard_of > 1 and world == 1:
                 lo, hi = drrt_dist.shard_bounds(args.rays, 0, args.shard_of)
@@ -577,7 +583,7 @@ def run_rank(args) -> int:
         ach_fwd = fwd_steps * B_FWD / (ms_fwd * 1e-3) / 1e9
         default_cfg = (R == 256 and n == 1024 * 1024 and world == 1 and not args.no_sort and not args.direct_atomics
                        and not args.experiment and args.pair == "auto" and not args.lds_bricks and not args.fwd_flags
-                       and not args.adj_flags and args.workload == "metric")
+                       and not args.adj_flags and args.workload == "metric" and args.source_axis == "y")
         pmc, pmc_src = load_pmc() if default_cfg else (None, None)
         pk_adj = pmc_kernel(pmc, "drrt::k_backtrace_flat", "drrt::k_backtrace_win")
         pk_fwd = pmc_kernel(pmc, "drrt::k_trace_flat", "drrt::k_trace<0>")
