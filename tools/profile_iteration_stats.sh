@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of tools/bench_iteration.py (a whole optimisation iteration, 4 views): per-kernel time of the
-# full flow.  Output: gpurun_out/prof_iter/ ; the summary is copied to profiles/r2_iteration_kernel_stats.csv.
+# full flow.  Output: gpurun_out/prof_iter/ ; the summary is copied to profiles/rN_iteration_kernel_stats.csv.
 set -o pipefail
 out=gpurun_out/prof_iter; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
