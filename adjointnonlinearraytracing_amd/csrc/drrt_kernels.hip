@@ -1188,6 +1188,9 @@ __device__ __forceinline__ bool bundles_want_ring(const unsigned* __restrict__ s
   return sel[0] * 100u >= sel[1] * (unsigned)DRRT_RING_MIN_NOFIT_PCT && sel[0] != 0u;
 }
 __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
+  __shared__ unsigned s_cnt[4];                  // the block's four counters: one set of global atomics per block, not per wave
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
   const Vol& V = a.vol;
   const size_t t = (size_t)blockIdx.x * kClassifyStride * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
@@ -1204,22 +1207,23 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
   const int y0 = wave_min_i32(ok ? cy : big), y1 = wave_max_i32(ok ? cy : -big);
   const int z0 = wave_min_i32(ok ? cz : big), z1 = wave_max_i32(ok ? cz : -big);
   const unsigned lanes = (unsigned)__popcll(__ballot(ok));
-  if (lanes == 0u) return;                                                   // (wave-uniform)
   // mean cell of the bundle (rounded); cells are < 2^24 per axis, 64 of them fit an int
-  const float inv = 1.0f / (float)lanes;
+  const float inv = 1.0f / (float)max(lanes, 1u);
   const int mx = (int)floorf((float)(int)wave_sum_u32(ok ? (unsigned)cx : 0u) * inv + 0.5f);
   const int my = (int)floorf((float)(int)wave_sum_u32(ok ? (unsigned)cy : 0u) * inv + 0.5f);
   const int mz = (int)floorf((float)(int)wave_sum_u32(ok ? (unsigned)cz : 0u) * inv + 0.5f);
   const bool far = ok && (abs(cx - mx) > kClassifyReach || abs(cy - my) > kClassifyReach || abs(cz - mz) > kClassifyReach);
   const unsigned outside = (unsigned)__popcll(__ballot(far));
-  if (lane == 0) {
+  if (lane == 0 && lanes != 0u) {
     const int ex = x1 - x0 + 2, ey = y1 - y0 + 2, ez = z1 - z0 + 2;           // slots per axis
     const bool dflt = (ex <= kWinX - 2) & (ey <= kWinY - 2) & (ez <= kWinZ - 2);   // two slots of room for the placement
-    if (!dflt) atomicAdd(&a.select[0], 1u);
-    atomicAdd(&a.select[1], 1u);
-    if (outside) atomicAdd(&a.select[2], outside);
-    atomicAdd(&a.select[3], lanes);
+    if (!dflt) atomicAdd(&s_cnt[0], 1u);
+    atomicAdd(&s_cnt[1], 1u);
+    if (outside) atomicAdd(&s_cnt[2], outside);
+    atomicAdd(&s_cnt[3], lanes);
   }
+  __syncthreads();
+  if (threadIdx.x < 4 && s_cnt[threadIdx.x] != 0u) atomicAdd(&a.select[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 #ifndef DRRT_ANCHOR_SHIFT
