@@ -36,9 +36,10 @@ constexpr int kBlock = 256;
 // ---------------------------------------------------------------------------------------------
 // stats: block-level reduction, then 3 atomics per block
 // ---------------------------------------------------------------------------------------------
+template <int BLOCK = kBlock>
 __device__ __forceinline__ void block_stats(drrt_stats* stats, unsigned steps, unsigned failed) {
   if (!stats) return;
-  __shared__ unsigned s_sum[kBlock / kWave], s_max[kBlock / kWave], s_fail[kBlock / kWave];
+  __shared__ unsigned s_sum[BLOCK / kWave], s_max[BLOCK / kWave], s_fail[BLOCK / kWave];
   unsigned ws = wave_sum_u32(steps), wm = wave_max_u32(steps), wf = wave_sum_u32(failed);
   int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   if (lane == 0) { s_sum[wid] = ws; s_max[wid] = wm; s_fail[wid] = wf; }
@@ -46,7 +47,7 @@ __device__ __forceinline__ void block_stats(drrt_stats* stats, unsigned steps, u
   if (threadIdx.x == 0) {
     unsigned long long sum = 0, fail = 0; unsigned mx = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / kWave; ++w) { sum += s_sum[w]; fail += s_fail[w]; mx = max(mx, s_max[w]); }
+    for (int w = 0; w < BLOCK / kWave; ++w) { sum += s_sum[w]; fail += s_fail[w]; mx = max(mx, s_max[w]); }
     if (sum)  atomicAdd(&stats->ray_steps, sum);
     if (fail) atomicAdd(&stats->n_failed, fail);
     if (mx)   atomicMax(&stats->iters, mx);
@@ -74,13 +75,13 @@ __device__ __forceinline__ bool ray_index(const uint32_t* __restrict__ perm, siz
 // One run per XCD hands whole VIEWS to single XCDs -- views differ in length and cost, and the launch then waits for the
 // XCD that drew the oblique ones -- so it is not used.  Runs of 16 for the forward march and the ring adjoint, blockIdx
 // order for the box adjoint (not bound by its gathers).
-enum { kXcdOff = 0, kXcdWhole = 1, kXcdRuns16 = 2 };
+enum { kXcdOff = 0, kXcdWhole = 1, kXcdRuns16 = 2, kXcdRuns64 = 3 };
 #ifndef DRRT_RING_XCD_MODE
-#define DRRT_RING_XCD_MODE kXcdRuns16
+#define DRRT_RING_XCD_MODE kXcdRuns64
 #endif
 __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb, int mode) {
-  if (mode == kXcdRuns16) {            // groups of 8 * 16 consecutive blocks of the visit order: 16 for each XCD
-    constexpr unsigned C = 16u, G = 8u * C;
+  if (mode == kXcdRuns16 || mode == kXcdRuns64) {   // groups of 8 * C consecutive blocks of the visit order: C for each XCD
+    const unsigned C = mode == kXcdRuns16 ? 16u : 64u, G = 8u * C;    // (64 for the adjoint's one-wave blocks: the same 4096 rays)
     if (b >= nb / G * G) return b;
     const unsigned w = b % G;
     return b - w + (w & 7u) * C + (w >> 3);
@@ -735,6 +736,17 @@ constexpr int kWinPX = DRRT_WIN + DRRT_WIN_PAD;           // row pitch
 constexpr int kWinSY = kWinPX, kWinSZ = kWinPX * kWinY;   // LDS strides of y and z
 constexpr int kWinFloats = kWinSZ * kWinZ;                // 810 slots = 6.3 KiB per wave (9^3 window, pitch 10)
 constexpr int kWavesPerBlock = kBlock / kWave;
+// k_backtrace_flat and k_backtrace_ring run ONE wave per block: nothing in them is shared between the waves of a block (each
+// wave owns its window), and a block's LDS and wave slots come free only when its last wave has finished -- with four waves of
+// different lengths per block that held resources idle.  Measured, same box, 256 / 128 / 64 threads per block (all kernels):
+// box-window adjoint 4.63-4.65 / 4.61-4.67 / 4.54-4.58 ms, ring-window adjoint on the six rotated views 8.84-8.98 / 8.70-8.98 /
+// 8.60-8.72 ms, forward march 0.99-1.00 / 1.02 / 1.02-1.03 ms (it keeps 256).
+#ifndef DRRT_ADJ_BLOCK
+#define DRRT_ADJ_BLOCK 64
+#endif
+constexpr int kAdjBlock = DRRT_ADJ_BLOCK;
+constexpr int kAdjWavesPerBlock = kAdjBlock / kWave;
+static inline unsigned adj_grid_for(size_t n) { return (unsigned)((n + kAdjBlock - 1) / kAdjBlock); }
 
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1242,17 +1254,17 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
 // MODE: 0 = backtrace, 1 = backtrace_sdf (the ray also ends where the sdf sample turns non-negative, :488-497; the sdf
 //       taps ride along with the grid's taps).
 template <bool ABL, bool PAIR, int MODE = 0>
-__global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackArgs a) {
+__global__ void __launch_bounds__(kAdjBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackArgs a) {
   if (a.select != nullptr && bundles_want_ring(a.select)) return;
   constexpr int kSlots = kWinFloats;
-  __shared__ win_t s_win[kWavesPerBlock][kSlots];
+  __shared__ win_t s_win[kAdjWavesPerBlock][kSlots];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   win_t* win = s_win[wid];
   for (int k = lane; k < kSlots; k += kWave) win[k] = (win_t)0;
   wave_lds_fence();
 
   const Vol& V = a.vol;
-  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;            // (XCD-aware orders measured no better here: xcd_block)
+  const size_t t = (size_t)blockIdx.x * kAdjBlock + threadIdx.x;         // (XCD-aware orders measured no better here: xcd_block)
   AdjState s;
   s.x = s.y = s.z = s.vx = s.vy = s.vz = s.lx = s.ly = s.lz = s.mx = s.my = s.mz = 0.f;
   s.active = false; s.outside = false;
@@ -1533,7 +1545,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackA
     if (ev_wsteps) atomicAdd(&a.dbg[8], (unsigned long long)ev_wsteps);
     if (ev_multi) atomicAdd(&a.dbg[9], (unsigned long long)ev_multi);
   }
-  block_stats(a.stats, steps, 0u);
+  block_stats<kAdjBlock>(a.stats, steps, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1721,19 +1733,19 @@ __device__ __forceinline__ bool ring_cross(win_t* win, int experiment, bool pre,
 }
 
 template <bool ABL, bool PAIR, int MODE = 0>
-__global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(BackArgs a) {
+__global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(BackArgs a) {
   if (a.select != nullptr) {                                 // launched next to k_backtrace_flat: the bundle
     const bool want_fit = bundles_want_ring(a.select);                                // classification picks one of the two
     if (!want_fit) return;
   }
-  __shared__ win_t s_win[kWavesPerBlock][kRingCap];
+  __shared__ win_t s_win[kAdjWavesPerBlock][kRingCap];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   win_t* win = s_win[wid];
   for (int k = lane; k < kRingCap; k += kWave) win[k] = (win_t)0;
   wave_lds_fence();
 
   const Vol& V = a.vol;
-  const size_t t = (size_t)xcd_block(blockIdx.x, gridDim.x, a.xcd_order ? DRRT_RING_XCD_MODE : kXcdOff) * kBlock + threadIdx.x;
+  const size_t t = (size_t)xcd_block(blockIdx.x, gridDim.x, a.xcd_order ? DRRT_RING_XCD_MODE : kXcdOff) * kAdjBlock + threadIdx.x;
   AdjState s;
   s.x = s.y = s.z = s.vx = s.vy = s.vz = s.lx = s.ly = s.lz = s.mx = s.my = s.mz = 0.f;
   s.active = false; s.outside = false;
@@ -2155,7 +2167,7 @@ __global__ void __launch_bounds__(kBlock, DRRT_RING_WAVES) k_backtrace_ring(Back
     if (ev_all8g) atomicAdd(&a.dbg[14], (unsigned long long)ev_all8g);
     if (ev_nopre) atomicAdd(&a.dbg[15], (unsigned long long)ev_nopre);
   }
-  block_stats(a.stats, steps, 0u);
+  block_stats<kAdjBlock>(a.stats, steps, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2743,7 +2755,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
       hipLaunchKernelGGL(k_backtrace_direct<MODE>, dim3(grid_for(n)), dim3(kBlock), 0, s, a);
     else if (!(flags & DRRT_FLAG_LEGACY_ADJOINT)) {
       const bool abl = a.experiment != 0 || a.dbg != nullptr, pair = a.vol.pair != nullptr;
-      const dim3 g(grid_for(n));
+      const dim3 g(adj_grid_for(n));
       // Two kernels: k_backtrace_flat with its compile-time 9^3 box window for compact bundles, k_backtrace_ring (fitted ring
       // window, step hint) for the rest.  With a visit order the bundles are classified on the device and BOTH are launched;
       // the one the counters do not pick returns at once (no host round trip).  Needs the 512-byte counter block at the end
@@ -2757,24 +2769,24 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
         g_last_counters = a.select;
         hipError_t e = hipMemsetAsync(a.select, 0, 16, s);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(select)");
-        hipLaunchKernelGGL(k_bundle_classify, dim3((g.x + kClassifyStride - 1) / kClassifyStride), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(k_bundle_classify, dim3((grid_for(n) + kClassifyStride - 1) / kClassifyStride), dim3(kBlock), 0, s, a);
       }
       if (!force_ring) {
         if (abl && MODE == 0) {
-          if (pair) hipLaunchKernelGGL((k_backtrace_flat<true, true, 0>), g, dim3(kBlock), 0, s, a);
-          else      hipLaunchKernelGGL((k_backtrace_flat<true, false, 0>), g, dim3(kBlock), 0, s, a);
+          if (pair) hipLaunchKernelGGL((k_backtrace_flat<true, true, 0>), g, dim3(kAdjBlock), 0, s, a);
+          else      hipLaunchKernelGGL((k_backtrace_flat<true, false, 0>), g, dim3(kAdjBlock), 0, s, a);
         } else {    /* the ablation / counter instantiation exists for backtrace only */
-          if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true, MODE>), g, dim3(kBlock), 0, s, a);
-          else      hipLaunchKernelGGL((k_backtrace_flat<false, false, MODE>), g, dim3(kBlock), 0, s, a);
+          if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true, MODE>), g, dim3(kAdjBlock), 0, s, a);
+          else      hipLaunchKernelGGL((k_backtrace_flat<false, false, MODE>), g, dim3(kAdjBlock), 0, s, a);
         }
       }
       if (force_ring || a.select != nullptr) {
         if (abl && MODE == 0) {
-          if (pair) hipLaunchKernelGGL((k_backtrace_ring<true, true, 0>), g, dim3(kBlock), 0, s, a);
-          else      hipLaunchKernelGGL((k_backtrace_ring<true, false, 0>), g, dim3(kBlock), 0, s, a);
+          if (pair) hipLaunchKernelGGL((k_backtrace_ring<true, true, 0>), g, dim3(kAdjBlock), 0, s, a);
+          else      hipLaunchKernelGGL((k_backtrace_ring<true, false, 0>), g, dim3(kAdjBlock), 0, s, a);
         } else {
-          if (pair) hipLaunchKernelGGL((k_backtrace_ring<false, true, MODE>), g, dim3(kBlock), 0, s, a);
-          else      hipLaunchKernelGGL((k_backtrace_ring<false, false, MODE>), g, dim3(kBlock), 0, s, a);
+          if (pair) hipLaunchKernelGGL((k_backtrace_ring<false, true, MODE>), g, dim3(kAdjBlock), 0, s, a);
+          else      hipLaunchKernelGGL((k_backtrace_ring<false, false, MODE>), g, dim3(kAdjBlock), 0, s, a);
         }
       }
     }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How much of the adjoint kernel's time is dispatch order?  The forward march leaves each ray's iteration count
 (`last_order.drrt_steps`), so the length of every adjoint wave is known before the adjoint is launched.  This probe list-
-schedules the blocks (4 waves, duration = its longest wave incl. the step-hint delay) on the chip's block slots in
+schedules the blocks (the 4-wave blocks the adjoint kernels had when this was measured; duration = its longest wave) on the chip's block slots in
 dispatch order and longest-first, for the bench's ray sets.  -> stdout (JSON lines)"""
 import sys, json, heapq
 import numpy as np
