@@ -73,15 +73,20 @@ __device__ __forceinline__ bool ray_index(const uint32_t* __restrict__ perm, siz
 //   ring-window adjoint, six rotated views    8.92-9.09 / 8.74-8.85 / 9.11-9.35 / 8.62-8.84 ms
 //   ring-window adjoint, 4 tomography views   5.30-5.32 / 5.23-5.25 / -- / 5.89-5.90 ms
 // One run per XCD hands whole VIEWS to single XCDs -- views differ in length and cost, and the launch then waits for the
-// XCD that drew the oblique ones -- so it is not used.  Runs of 16 for the forward march and the ring adjoint, blockIdx
-// order for the box adjoint (not bound by its gathers).
-enum { kXcdOff = 0, kXcdWhole = 1, kXcdRuns16 = 2, kXcdRuns64 = 3 };
+// XCD that drew the oblique ones -- so it is not used.  (Those rows were measured with 256-thread blocks everywhere.)  Since
+// the adjoint kernels run one wave per block (kAdjBlock), consecutive WAVES would land on different XCDs in blockIdx order:
+// runs of 16 one-wave blocks per XCD, same box: box adjoint 4.52-4.57 -> 4.49-4.50 ms (runs of 64: no change), ring adjoint on
+// the six rotated views 8.64-8.66 (runs of 64) -> 8.47-8.63 ms.  Runs of 16 for all three march kernels.
+enum { kXcdOff = 0, kXcdWhole = 1, kXcdRuns16 = 2 };
+#ifndef DRRT_FLAT_XCD_MODE
+#define DRRT_FLAT_XCD_MODE kXcdRuns16
+#endif
 #ifndef DRRT_RING_XCD_MODE
-#define DRRT_RING_XCD_MODE kXcdRuns64
+#define DRRT_RING_XCD_MODE kXcdRuns16
 #endif
 __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb, int mode) {
-  if (mode == kXcdRuns16 || mode == kXcdRuns64) {   // groups of 8 * C consecutive blocks of the visit order: C for each XCD
-    const unsigned C = mode == kXcdRuns16 ? 16u : 64u, G = 8u * C;    // (64 for the adjoint's one-wave blocks: the same 4096 rays)
+  if (mode == kXcdRuns16) {            // groups of 8 * 16 consecutive blocks of the visit order: 16 for each XCD
+    constexpr unsigned C = 16u, G = 8u * C;
     if (b >= nb / G * G) return b;
     const unsigned w = b % G;
     return b - w + (w & 7u) * C + (w >> 3);
@@ -1264,7 +1269,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_ADJ_WAVES) k_backtrace_flat(Ba
   wave_lds_fence();
 
   const Vol& V = a.vol;
-  const size_t t = (size_t)blockIdx.x * kAdjBlock + threadIdx.x;         // (XCD-aware orders measured no better here: xcd_block)
+  const size_t t = (size_t)xcd_block(blockIdx.x, gridDim.x, a.xcd_order ? DRRT_FLAT_XCD_MODE : kXcdOff) * kAdjBlock + threadIdx.x;
   AdjState s;
   s.x = s.y = s.z = s.vx = s.vy = s.vz = s.lx = s.ly = s.lz = s.mx = s.my = s.mz = 0.f;
   s.active = false; s.outside = false;
