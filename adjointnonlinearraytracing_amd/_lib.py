@@ -21,14 +21,9 @@ FLAG_CORRECTED_H = 2
 FLAG_NO_ZERO = 4
 FLAG_DIRECT_ATOMICS = 8
 FLAG_DEBUG_COUNTERS = 16
-FLAG_LDS_BRICKS = 32
 FLAG_PAIR_GRID = 64
 FLAG_PAIR_REUSE = 128
 FLAG_QUAD_GRID, FLAG_QUAD_REUSE = FLAG_PAIR_GRID, FLAG_PAIR_REUSE      # round-1 names
-FLAG_TAP_REUSE_OFF, FLAG_TAP_REUSE_FACE = 0x10000, 0x20000
-FLAG_NO_PIPELINE = 0x40000
-FLAG_LEGACY_ADJOINT = 0x80000
-FLAG_LEGACY_FORWARD = 0x100000
 FLAG_Q16_POS_ONLY = 0x200000
 FLAG_STATIC_WINDOW = 0x400000
 FLAG_CHORD_KEY = 0x800000

@@ -436,7 +436,7 @@ DRRT_HD void adj_init(const Vol& V, float ds, float dxx, float dxy, float dxz,
 }
 
 // One adjoint iteration is split in two halves so that the windowed kernel can issue the NEXT sample's gather
-// between them (software pipelining, drrt_kernels.hip k_backtrace_win); adj_step below is the plain sequence.
+// between them (software pipelining, k_backtrace_flat / k_backtrace_ring); adj_step below is the plain sequence.
 struct AdjSample { float n, gx, gy, gz, hxy, hxz, hyz; };   // n, grad n (scaled by 1/h), mixed partials (raw)
 
 // First half (src/tracer.cpp:421-425; sdf :488-497): sample the cell `c` the ray has just stepped into (taps `t`),
@@ -595,7 +595,7 @@ DRRT_HD bool cable_adj_step(const Cyl& C, float ds, AdjState& s, int& i0, int& i
 // ---------------------------------------------------------------------------------------------
 struct RayOut { float xt[3], vt[3]; float dist2; bool esc, act, again; unsigned steps; };
 
-// trace / trace_plane / trace_sdf for ONE ray, per-ray termination (see drrt_kernels.hip header)
+// trace / trace_plane / trace_sdf for ONE ray, per-ray termination (see drrt_march.h header)
 constexpr int kTapReuse = 1;      // product default of the forward marches (see fetch_reuse): measured on MI355X, 256^3 /
                                   // 1M rays: no reuse 1.47 ms, same-cell 1.31 ms, + shared-face 1.68 ms (its branches cost
                                   // more issue slots than the two pair loads they save)

@@ -35,11 +35,9 @@ class Options:
     check_failed: bool = True     # print "failed to exit all rays" like src/tracer.cpp:89-90 (asynchronously: no host
                                   # sync per call; the message may appear one call late -- see flush_warnings())
     direct_atomics: bool = False  # adjoint: one global atomic per tap (debug / A-B)
-    legacy_adjoint: bool = False  # adjoint: the round-1 window kernel instead of k_backtrace_flat (DRRT_FLAG_LEGACY_ADJOINT, A-B)
     adjoint_window: str = "auto"  # adjoint: "auto" = the bundles of the call are classified on the device and the box-window kernel
                                   # (k_backtrace_flat) or the ring-window kernel (k_backtrace_ring) runs; "box" / "ring" force one
     chord_key: bool = False       # locality sort with the rounds-1/2 key (DRRT_FLAG_CHORD_KEY, A-B)
-    lds_bricks: bool = False      # forward: opt-in LDS-staged bricks of the grid (bit-identical; slower on MI355X)
     pair_grid: object = "auto"    # the "pair copy" of the grid in the workspace (DRRT_FLAG_PAIR_GRID; 8 bytes per voxel, two
                                   # 16-byte gathers per cell instead of four 8-byte ones).  True, False, or "auto" = a
                                   # forward march builds it when the call keeps the whole GPU busy and does enough
@@ -104,16 +102,12 @@ def _flags(adjoint: bool = False) -> int:
         f |= _lib.FLAG_CORRECTED_H
     if adjoint and _opt().direct_atomics:
         f |= _lib.FLAG_DIRECT_ATOMICS
-    if adjoint and _opt().legacy_adjoint:
-        f |= _lib.FLAG_LEGACY_ADJOINT
     if adjoint and _opt().adjoint_window == "box":
         f |= _lib.FLAG_STATIC_WINDOW
     if adjoint and _opt().adjoint_window == "ring":
         f |= _lib.FLAG_RING_WINDOW
     if _opt().chord_key:
         f |= _lib.FLAG_CHORD_KEY
-    if not adjoint and _opt().lds_bricks:
-        f |= _lib.FLAG_LDS_BRICKS
     if adjoint and _EXPERIMENT:
         f |= (_EXPERIMENT & 0xFF) << 8          # development ablations of the adjoint kernel (include/drrt_hip.h)
     return f
@@ -156,7 +150,7 @@ def _march_workspace(rif_: torch.Tensor, res, n: int, h: float, ds: float, flags
         ok = float(ds) > 0.0 and float(h) > 0.0               # invalid steps are the library's to report
         q = ok and n >= _PAIR_AUTO_MIN_RAYS and \
             n * max(int(r) for r in res) * (float(h) / float(ds)) >= 8.0 * rif_.numel()
-    if not q or (flags & _lib.FLAG_LDS_BRICKS) or n == 0:
+    if not q or n == 0:
         return flags, _workspace(n, flags, device)
     pflags = flags | _lib.FLAG_PAIR_GRID
     key = (rif_.data_ptr(), rif_._version, rif_.numel(), n, flags & _lib.FLAG_SORT_RAYS)

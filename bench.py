@@ -72,7 +72,6 @@ def parse_args(argv=None):
                     help="default: strong for --gpus 1, both for --gpus > 1")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--direct-atomics", action="store_true")
-    ap.add_argument("--lds-bricks", action="store_true", help="forward: opt-in LDS-staged grid bricks")
     ap.add_argument("--no-step-hint", action="store_true", help="adjoint rays start at their own exit sample (A-B)")
     ap.add_argument("--no-order-reuse", action="store_true",
                     help="adjoint computes its own visit order instead of reusing the forward's")
@@ -411,7 +410,7 @@ def run_rank(args) -> int:
     flags = 0 if args.no_sort else _lib.FLAG_SORT_RAYS
     if args.quad:
         args.pair = "on"
-    fflags0 = flags | (_lib.FLAG_LDS_BRICKS if args.lds_bricks else 0) | args.fwd_flags
+    fflags0 = flags | args.fwd_flags
     aflags0 = flags | (_lib.FLAG_DIRECT_ATOMICS if args.direct_atomics else 0) | args.adj_flags
     aflags0 |= (_lib.FLAG_DEBUG_COUNTERS if args.debug_counters else 0) | ((args.experiment & 0xff) << 8)
 
@@ -421,7 +420,7 @@ def run_rank(args) -> int:
         from adjointnonlinearraytracing_amd import drrt as _drrt
         use = args.pair == "on" or (args.pair == "auto" and n >= _drrt._PAIR_AUTO_MIN_RAYS
                                     and n * R * (h / ds) >= 8.0 * nvox)
-        if not use or args.lds_bricks or n == 0:
+        if not use or n == 0:
             return fflags0, aflags0, False
         return fflags0 | _lib.FLAG_PAIR_GRID, aflags0 | _lib.FLAG_PAIR_GRID | _lib.FLAG_PAIR_REUSE, True
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -582,7 +581,7 @@ def run_rank(args) -> int:
         ach_adj = adj_steps * B_ADJ / (ms_adj * 1e-3) / 1e9
         ach_fwd = fwd_steps * B_FWD / (ms_fwd * 1e-3) / 1e9
         default_cfg = (R == 256 and n == 1024 * 1024 and world == 1 and not args.no_sort and not args.direct_atomics
-                       and not args.experiment and args.pair == "auto" and not args.lds_bricks and not args.fwd_flags
+                       and not args.experiment and args.pair == "auto" and not args.fwd_flags
                        and not args.adj_flags and args.workload == "metric" and args.source_axis == "y")
         pmc, pmc_src = load_pmc() if default_cfg else (None, None)
         pk_adj = pmc_kernel(pmc, "drrt::k_backtrace_flat", "drrt::k_backtrace_win")

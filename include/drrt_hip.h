@@ -47,7 +47,8 @@ extern "C" {
 #define DRRT_ERR_ARG          (-3)  /* null pointer / workspace too small / bad flag             */
 #define DRRT_ERR_HIP          (-4)  /* a HIP runtime call failed (message carries hipGetErrorString) */
 
-/* flags (bit-or) */
+/* flags (bit-or).  Bits 32u, 0x10000u..0x100000u carried A-B switches for kernels that were removed in round 4 (LDS
+ * bricks, tap-reuse variants, the round-1 forward / adjoint kernels); they are ignored now. */
 #define DRRT_FLAG_NONE         0u
 #define DRRT_FLAG_SORT_RAYS    1u   /* locality-sort rays by entry voxel before marching (results
                                        are written back in the caller's ray order)                */
@@ -60,10 +61,6 @@ extern "C" {
 #define DRRT_FLAG_DIRECT_ATOMICS 8u /* adjoint only: bypass the LDS gradient windows and issue
                                        one global atomic per tap (debug / A-B measurement)        */
 
-#define DRRT_FLAG_LDS_BRICKS   32u  /* forward only (opt-in): stage per-wave bricks of the grid in LDS and
-                                       read the taps from there instead of gathering from global
-                                       memory every step.  Bit-identical results; measured slower than
-                                       the default L1-served pair gathers on MI355X   */
 #define DRRT_FLAG_PAIR_GRID    64u  /* trace / trace_pln / trace_sdf / backtrace*: build the "pair copy" of the grid in the
                                        workspace (8 B per voxel: each voxel interleaved with its +y neighbour) and
                                        fetch the 8 corners of a strictly interior cell with two 16-byte loads instead
@@ -76,15 +73,8 @@ extern "C" {
                                        e.g. the adjoint paired with its forward: skip the rebuild                  */
 #define DRRT_FLAG_QUAD_GRID  DRRT_FLAG_PAIR_GRID    /* round-1 names (the copy then held an (x,y) quad per voxel)   */
 #define DRRT_FLAG_QUAD_REUSE DRRT_FLAG_PAIR_REUSE
-#define DRRT_FLAG_TAP_REUSE_MASK 0x30000u /* trace / trace_pln / trace_sdf (A-B measurement; results are bit-identical):   */
-#define DRRT_FLAG_TAP_REUSE_OFF  0x10000u /*   gather all 8 taps at every step                                              */
-#define DRRT_FLAG_TAP_REUSE_FACE 0x20000u /*   also keep the shared face across a y- or z-move (2 pair loads instead of 4)  */
-                                          /*   default (0): skip the gather while the ray stays in the same cell            */
-#define DRRT_FLAG_NO_PIPELINE 0x40000u    /* backtrace / backtrace_sdf (A-B measurement; same results): the window kernel's
-                                             loop without software pipelining (sample, bookkeeping, then step) */
 #define DRRT_FLAG_Q16_POS_ONLY 0x200000u  /* drrt_trace_q16io / drrt_backtrace_q16io: only the POSITION arrays are q16 codes;
                                              directions and adjoint seeds are fp32 arrays (18 B per exit ray instead of 12) */
-#define DRRT_FLAG_LEGACY_FORWARD 0x100000u /* trace, trace_pln, trace_target (A-B measurement; bit-identical results): k_trace<MODE> / k_target_a instead of the flat kernels */
 #define DRRT_FLAG_CHORD_KEY 0x800000u      /* with SORT_RAYS (A-B measurement; same results): the rounds-1/2 sort key (6-D Morton interleave of the
                                               chord end points) instead of the light-field key (direction cell + Hilbert index of the
                                               transverse offset, csrc/drrt_sort.hip) */
@@ -99,14 +89,11 @@ extern "C" {
                                          up to fp32 summation order): block b of a launch marches block b of the visit order.  Default
                                          with a visit order: each of the chip's 8 XCDs (own L2; blocks are dealt to them round-robin)
                                          takes a contiguous run of the visit order, so neighbouring bundles share one L2 */
-#define DRRT_FLAG_LEGACY_ADJOINT 0x80000u /* backtrace, backtrace_sdf (A-B measurement; same results up to fp32 summation order): the round-1
-                                             window kernel k_backtrace_win instead of the reorganised k_backtrace_flat */
 #define DRRT_FLAG_DEBUG_COUNTERS 16u /* adjoint only (development aid): uint64 counters are
                                        written to the last 512 bytes of the workspace:
                                        [0] LDS-window flushes, [1] ray-steps accumulated through
                                        the LDS window, [2] ray-steps that fell back to global atomics
-                                       ([1], [2]: round-1 kernel only), [3] waves that ran with
-                                       run-time window dimensions (fitted windows);
+                                       ([1], [2]: unused since round 4), [3] waves of the ring-window kernel;
                                        k_backtrace_flat events: [4] one-face cell leaves handed to the
                                        window, [5] lanes of those that issued the LDS adds after the
                                        pair / quad pre-reduction, [6] one-face leaves sent to global

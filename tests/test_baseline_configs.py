@@ -35,6 +35,26 @@ def _plane_source3(num, width):
     return pos, vel
 
 
+def _adjoint_vs_allcores_oracle(D, oracle, T, rif_d, res, pos_d, vel_d, h, ds):
+    """Forward + adjoint (dx = dv = 1) of ALL rays through the drop-in API, against the all-cores oracle in the kernels'
+    arithmetic: exit rays bit-exact, step totals equal, rel-L2(dL/dn) <= 2e-5 (src/tracer.cpp:35-100,384-440)."""
+    xt, vt = T.trace(rif_d, res, pos_d, vel_d, h, ds)
+    fwd = D.read_stats()
+    order = D.last_order
+    ones = torch.ones_like(xt)
+    g = T.backtrace(rif_d, res, xt, vt, ones, ones, h, ds, order=order)
+    adj = D.read_stats()
+    threads = max(1, min(len(os.sched_getaffinity(0)), 32))
+    with oracle.arith("factored"):
+        o = oracle.bench_allcores(rif_d.cpu().numpy(), res, pos_d.cpu().numpy(), vel_d.cpu().numpy(), h, ds, threads,
+                                  want_rays=True)
+    assert np.array_equal(xt.cpu().numpy(), o["xt"]) and np.array_equal(vt.cpu().numpy(), o["vt"])
+    assert fwd["ray_steps"] == o["fwd_steps"] and adj["ray_steps"] == o["adj_steps"]
+    rel = cases.rel_l2(g.cpu().numpy(), o["grad"])
+    assert rel <= 2e-5, rel
+    return rel
+
+
 def test_config0_luneburg_forward_32cube_16k_rays_via_TracerS(gpu, oracle, D):
     """configs[0]: Luneburg lens forward render, 32^3 grid, 16k rays, the reference's CPU-class plumbing
     (drrt.TracerS binds trace only with CPU tensors, src/drrt.cpp:38-45).  Here TracerS stages the
@@ -82,7 +102,8 @@ def test_config1_luneburg_128cube_256k_rays_fwd_adjoint(gpu, oracle, D):
 def test_config2_tomography_65cube_1M_rays_4_shards(gpu, oracle, D):
     """configs[2]: fuel-injection-like field (n in [1, 1.0003]) on 65^3, 1M rays from three views, sharded
     4 ways with the dL/dn grids summed (what the RCCL all-reduce does): shard sum == single pass; a
-    strided sub-sample of rays is checked bit-exactly against the oracle."""
+    strided sub-sample of rays is checked bit-exactly against the oracle, and the adjoint of the whole set (dx = dv = 1)
+    against the all-cores oracle."""
     R, span, per_view = 65, 1.0, 349525
     h = span / (R - 1); ds = h / 2
     rif = (1.0 + 3e-4 * (cases.smooth_field(R, seed=6, amp=1.0) - 1.0)).astype(np.float32)
@@ -107,11 +128,14 @@ def test_config2_tomography_65cube_1M_rays_4_shards(gpu, oracle, D):
         lo, hi = r * n // 4, (r + 1) * n // 4
         acc += T.backtrace(rif_d, rif.shape, xt[lo:hi], vt[lo:hi], dx[lo:hi], dv[lo:hi], h, ds)
     assert cases.rel_l2(acc.cpu().numpy(), full.cpu().numpy()) <= 2e-5
+    # the adjoint of ALL 1 048 575 rays of the three views against the all-cores oracle (round-3 review, item 3a)
+    _adjoint_vs_allcores_oracle(D, oracle, T, rif_d.reshape(-1), rif.shape, pos_d, vel_d, h, ds)
 
 
 def test_config3_fiber_and_256cube_4M_rays(gpu, oracle, D):
     """configs[3]: (i) cable variant, 257-sample radial profile, 4M rays x ~512 steps; (ii) generic march on
-    256^3 with 4M rays.  Sub-samples bit-exact vs the oracle; adjoint linear in its seed."""
+    256^3 with 4M rays.  Fibre: sub-samples bit-exact vs the oracle, adjoint linear in its seed; generic march: a
+    forward sub-sample, then forward + adjoint of all 4M rays against the all-cores oracle."""
     # (i) fibre
     rres, radius = 257, 1.0
     ds = radius / rres / 2                                              # core/fiber_opt.py:156
@@ -150,6 +174,9 @@ def test_config3_fiber_and_256cube_4M_rays(gpu, oracle, D):
         o = oracle.trace(rif.cpu().numpy(), rif.shape, p1[sub].cpu().numpy(), v1[sub].cpu().numpy(), h, dsv,
                          dtype=np.float32)
     assert np.array_equal(xt[sub].cpu().numpy(), o["xt"])
+    # ... and the adjoint of ALL 4 194 304 rays against the all-cores oracle (round-3 review, item 3a)
+    del xt, vt
+    _adjoint_vs_allcores_oracle(D, oracle, T, rif.reshape(-1), tuple(rif.shape), p1, v1, h, dsv)
 
 
 def test_config4_image_caustic_fp16_rays_512_sensor(gpu, D):

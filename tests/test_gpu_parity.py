@@ -101,36 +101,6 @@ def test_backtrace_matches_oracle(gpu, oracle, drrt_mod, kind, R, n, sort, corre
 
 
 @pytest.mark.parametrize("sort", [True, False])
-def test_lds_bricks_are_bit_identical_to_global_gathers(gpu, drrt_mod, sort):
-    """Forward march with per-wave LDS bricks of the grid (opt-in, DRRT_FLAG_LDS_BRICKS) vs the default
-    global pair gathers: the taps are the same floats, so exit rays, plane masks and step
-    counts must be identical.  Unsorted six-view rays exercise the out-of-brick fallback; the
-    tiny 5^3 grid exercises bricks larger than the volume."""
-    for R, n in ((65, 4000), (5, 500)):
-        span = 1.0
-        h = span / (R - 1); ds = h / 2
-        rif = _t(cases.smooth_field(R, seed=4), gpu)
-        pos, vel = cases.cube_rays(n, span, ds, seed=13, tilt=0.3)
-        po = np.tile(np.array([[0.5, 0.7, 0.5]], np.float32) * span, (len(pos), 1))
-        pd = np.tile(np.array([[0, 1, 0]], np.float32), (len(pos), 1))
-        T = drrt_mod.TracerC()
-        drrt_mod.options.sort_rays = sort
-        out = {}
-        for bricks in (True, False):
-            drrt_mod.options.lds_bricks = bricks
-            try:
-                xt, vt = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
-                st = drrt_mod.read_stats()
-                xp, vp, fm = T.trace_pln(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), _t(po, gpu), _t(pd, gpu), h, ds)
-            finally:
-                drrt_mod.options.lds_bricks = False
-            out[bricks] = (xt.cpu(), vt.cpu(), st, xp.cpu(), vp.cpu(), fm.cpu())
-        a, b = out[True], out[False]
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
-        assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
-
-
-@pytest.mark.parametrize("sort", [True, False])
 def test_quad_grid_copy_is_bit_identical(gpu, oracle, drrt_mod, sort):
     """DRRT_FLAG_QUAD_GRID (two 16-byte loads per interior cell from the quad copy) vs the plain grid: the
     taps are the same floats, so forward results are identical bit for bit and the adjoint differs only by
@@ -666,10 +636,9 @@ def test_order_hint_lifetime_and_range_check(gpu, drrt_mod):
     assert all(torch.equal(u, w) for u, w in zip(a, b))
 
 
-def test_bricks_plane_second_pass_matches_default(gpu, oracle, drrt_mod):
-    """with DRRT_FLAG_LDS_BRICKS trace_pln must flag the rays that can record a LATER exit
-    (start past the plane, head back through it) exactly like the default kernel, so that the second pass
-    re-marches them: compare both kernels with the oracle on such rays."""
+def test_plane_second_pass_on_plain_grid_and_pair_copy(gpu, oracle, drrt_mod):
+    """trace_pln must flag the rays that can record a LATER exit (start past the plane, head back through it) so
+    that the second pass re-marches them: both gather forms of k_trace_flat<., 1> against the oracle on such rays."""
     R, span = 17, 1.0
     h = span / (R - 1); ds = h / 2
     rif = cases.smooth_field(R, seed=9)
@@ -687,16 +656,14 @@ def test_bricks_plane_second_pass_matches_default(gpu, oracle, drrt_mod):
     T = drrt_mod.TracerC()
     for sort in (False, True):
         drrt_mod.options.sort_rays = sort
-        for bricks, pair in ((False, False), (True, False), (False, True)):
-            drrt_mod.options.lds_bricks = bricks
+        for pair in (False, True):
             drrt_mod.options.pair_grid = pair
             try:
                 xt, vt, fm = T.trace_pln(_t(rif, gpu), rif.shape, _t(pos, gpu), _t(vel, gpu), _t(po, gpu), _t(pd, gpu), h, ds)
             finally:
-                drrt_mod.options.lds_bricks = False
                 drrt_mod.options.pair_grid = "auto"
-            assert np.array_equal(xt.cpu().numpy(), ref["xt"]) and np.array_equal(vt.cpu().numpy(), ref["vt"]), (sort, bricks, pair)
-            assert np.array_equal(fm.cpu().numpy().astype(bool), ref["failmask"]), (sort, bricks, pair)
+            assert np.array_equal(xt.cpu().numpy(), ref["xt"]) and np.array_equal(vt.cpu().numpy(), ref["vt"]), (sort, pair)
+            assert np.array_equal(fm.cpu().numpy().astype(bool), ref["failmask"]), (sort, pair)
     drrt_mod.options.sort_rays = True
 
 
@@ -723,8 +690,8 @@ def test_failed_ray_warning_is_asynchronous_but_not_lost(gpu, drrt_mod, capsys):
 def test_adjoint_kernel_variants_agree(gpu, oracle, drrt_mod, kind, R, step_res):
     """The window kernels of drrt_backtrace_f32 -- k_backtrace_flat (box window), k_backtrace_ring (ring window; with the
     forward's visit order, and with the step hint that starts its rays on the forward march's clock), the device-side
-    choice between the two, both sort keys, k_backtrace_win with the software-pipelined loop (DRRT_FLAG_LEGACY_ADJOINT) and
-    without it (+ DRRT_FLAG_NO_PIPELINE) -- run the same per-ray arithmetic (adj_sample / adj_contrib): equal step counts,
+    choice between the two, both sort keys -- and the one-atomic-per-tap kernel (DRRT_FLAG_DIRECT_ATOMICS: no windows, no
+    register accumulators) run the same per-ray arithmetic (adj_sample / adj_contrib = adj_step): equal step counts,
     gradients equal up to the fp32 summation order, and each within 2e-5 of the oracle.  Steps larger than a cell and a 5^3 grid exercise the multi-face jumps and the
     clamped boundary cells; unsorted rays exercise the global-atomic fallback."""
     import ctypes as C
@@ -753,7 +720,7 @@ def test_adjoint_kernel_variants_agree(gpu, oracle, drrt_mod, kind, R, step_res)
     assert drrt_mod.last_order is not None and fsteps is not None and fsteps.numel() == n
     variants = [("flat", _lib.FLAG_STATIC_WINDOW), ("auto", 0), ("ring", _lib.FLAG_RING_WINDOW),
                 ("ring_chord", _lib.FLAG_RING_WINDOW | _lib.FLAG_CHORD_KEY), ("flat_chord", _lib.FLAG_STATIC_WINDOW | _lib.FLAG_CHORD_KEY),
-                ("win_pipe", _lib.FLAG_LEGACY_ADJOINT), ("win", _lib.FLAG_LEGACY_ADJOINT | _lib.FLAG_NO_PIPELINE)]
+                ("direct", _lib.FLAG_DIRECT_ATOMICS)]
     for name, fl in variants:
         for sort in (1, 0, "hint", "hint+steps"):
             flags = fl | (0 if sort == 0 else 1)
