@@ -92,6 +92,7 @@ SIGNATURES = {
     "drrt_last_steps": (_vp, [_vp]),
     "drrt_set_step_hint": (None, [_vp, _sz]),
     "drrt_last_bundle_counters": (_vp, []),
+    "drrt_ring_threshold_pct": (_i, []),
     "drrt_profile_begin": (_i, [_i]),
     "drrt_profile_collect": (_i, [_vp, _vp, _i]),
     "drrt_profile_end": (None, []),

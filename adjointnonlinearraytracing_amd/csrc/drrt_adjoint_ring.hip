@@ -59,6 +59,20 @@ namespace drrt {
                                     //   never sparse 9.9 / 5.9 / 5.0;  50 % -> 9.0 / 5.9 / 5.2;  70 % -> 8.9 / 6.8 / 5.7;  always sparse 8.9 / 8.8 / 5.9
 #endif
 constexpr int kRingCap = DRRT_RING_CAP;
+// Diagnostic build only (-DDRRT_RING_STAMPS, tools/ring_stamps.py; never in the product library): wave-level s_memtime
+// brackets around the regions of an iteration, summed over the launch -- where a wave's TIME goes (issue + waiting), which
+// the PMC instruction counts cannot say.  Stamp values go to a buffer of their own that nothing else reads.
+#if defined(DRRT_RING_STAMPS)
+__device__ unsigned long long g_ring_stamps[8];
+#define STAMP_DECL unsigned long long st_t = 0ull, st_acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; unsigned long long st_t0 = __builtin_amdgcn_s_memtime(); st_t = st_t0
+#define STAMP(k) { const unsigned long long st_n = __builtin_amdgcn_s_memtime(); st_acc[k] += st_n - st_t; st_t = st_n; }
+#define STAMP_END { const unsigned long long st_n = __builtin_amdgcn_s_memtime(); \
+    if (lane == 0) { atomicAdd(&g_ring_stamps[0], st_n - st_t0); for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_ring_stamps[1 + k_], st_acc[k_]); atomicAdd(&g_ring_stamps[7], 1ull); } }
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_END
+#endif
 struct Ring {                      // wave-uniform
   int nx, ny, nz;                  // slots per axis (>= 2)
   int sy, sz;                      // LDS strides of y and z in slots: nx, nx * ny
@@ -327,6 +341,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
     return ok & (lidx < 0) & nearby;
   };
 
+  STAMP_DECL;
   for (int it = 0; it < it_end; ++it) {
     if (!__any(s.active | pending)) break;                                    // wave-uniform exit
     if (a.fsteps != nullptr) {                                                // step hint (wave-uniform)
@@ -344,10 +359,14 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
           if (regular && experiment != 1) { if (emit8(lidx, base, sx, sy, sz)) dirty = true; }
           s.active = false;
         }
+        // `dirty` guards 64-lane cooperative flushes below: it has to be wave-uniform BEFORE the service of this very
+        // iteration looks at it (a lone expiring lane must not enter a flush on its own)
+        dirty = __ballot(dirty) != 0ull;
       }
     }
     // ---- lanes ahead of (or beside) the window: let it follow them (wave-uniform branch) ----
     const unsigned long long mm = __ballot(s.active & miss);
+    STAMP(0)                                                                  // top of the iteration, step hint
     if (mm != 0ull) {
       const bool ok = s.active & regular;
       const int big = 1 << 28;
@@ -477,6 +496,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
         }
       }
     }
+    STAMP(1)                                                                  // window service
     if (DRRT_RING_SIMPLE == 0 && (it & 15) == 15) {          // a sample of one iteration in 16 (scalar arithmetic only)
       const bool on = s.active & regular;
       const int pb = __builtin_amdgcn_update_dpp(-1, base, 0xB1, 0xF, 0xF, false);   // the pair partner's cell (quad_perm [1,0,3,2])
@@ -515,6 +535,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
           atomic_add_f32(g + cb.oz, w.c001);             atomic_add_f32(g + cb.oz + cb.ox, w.c101);
           atomic_add_f32(g + cb.oz + cb.oy, w.c011);     atomic_add_f32(g + cb.oz + cb.oy + cb.ox, w.c111);
         }
+        STAMP(2)                                             // sample (waits for the taps), weights, accumulate
         const int old_base = base, old_lidx = lidx;
         const bool old_regular = regular;
         int nbase; bool nregular;
@@ -537,6 +558,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
         s.ly = fmaf(a.ds, fmaf(dn, m.gy, m.n * hmy), s.ly);
         s.lz = fmaf(a.ds, fmaf(dn, m.gz, m.n * hmz), s.lz);
         s.mx = fmaf(a.ds, s.lx, s.mx); s.my = fmaf(a.ds, s.ly, s.my); s.mz = fmaf(a.ds, s.lz, s.mz);
+        STAMP(3)                                             // step, locate, gather issue, lambda / mu
         // ---- the ray leaves its cell ----
         if (nbase != old_base || !interior) {
           base = nbase; regular = nregular;
@@ -601,9 +623,12 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
         }
       }
     }
+    STAMP(4)                                                 // leave: hand-over, new slot
     dirty = dirty | (__ballot(used_lds) != 0ull);
     if (ABL && dbg) ev_wsteps += lane == 0;
   }
+  STAMP(5)
+  STAMP_END
   // rays still marching when max_steps ran out keep what their cell has accumulated: hand it over
   if (s.active && regular && experiment != 1) { if (emit8(lidx, base, sx, sy, sz)) dirty = true; }
   dirty = __ballot(dirty) != 0ull;
@@ -645,3 +670,14 @@ void launch_backtrace_ring(int mode, bool abl, const BackArgs& a, hipStream_t s)
 }
 
 }  // namespace drrt
+
+#if defined(DRRT_RING_STAMPS)
+extern "C" __attribute__((visibility("default"))) int drrt_debug_ring_stamps(unsigned long long* out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(drrt::g_ring_stamps), sizeof(drrt::g_ring_stamps)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(drrt::g_ring_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

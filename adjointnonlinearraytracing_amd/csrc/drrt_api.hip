@@ -62,6 +62,7 @@ extern "C" const uint32_t* drrt_last_steps(size_t* n_out) {
 extern "C" void drrt_set_step_hint(const uint32_t* steps, size_t n) { g_hint_steps = steps; g_hint_steps_n = steps ? n : 0; }
 static thread_local const unsigned* g_last_counters = nullptr;   // bundle classification of the last adjoint call (device, in its workspace)
 extern "C" const unsigned* drrt_last_bundle_counters(void) { return g_last_counters; }
+extern "C" int drrt_ring_threshold_pct(void) { return DRRT_RING_MIN_NOFIT_PCT; }
 
 // ---- optional per-kernel timing (bench / profiling aid; not thread-safe) --------------------
 // Event pairs are recorded on the call's stream right around a kernel launch; nothing

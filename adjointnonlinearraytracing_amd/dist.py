@@ -7,13 +7,13 @@ exchange step: every rank accumulates its rays' dL/dn into a private fp32 grid, 
 all-reduce(sum) over the grid (RCCL over xGMI with backend "nccl"; gloo on CPU for tests) gives
 every rank the full gradient, so replicated optimisers stay in lock-step.
 
-The march itself is pluggable (``local=`` argument) so the sharding / reduction logic is testable
-on CPU with gloo; the default is the HIP path (``drrt.TracerC``).
+The march is the HIP path (``drrt.TracerC``); the CPU tests (gloo, world 2) replace the two module-level
+functions that call it with stand-ins, so the sharding / reduction logic is testable without a GPU.
 """
 from __future__ import annotations
 
 import os
-from typing import Callable, List, Optional, Sequence, Tuple, Union
+from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
 import torch.distributed as dist
@@ -128,7 +128,7 @@ def _hip_trace(rif_flat, shape, x, v, h, ds):
     """-> (xt, vt, order): the forward's visit order rides along so the sharded adjoint can reuse it."""
     from . import drrt
     xt, vt = drrt.TracerC().trace(rif_flat, shape, x, v, h, ds)
-    return xt, vt, drrt.last_order
+    return xt, vt, drrt.keep_order(drrt.last_order)
 
 
 def _hip_backtrace(rif_flat, shape, xt, vt, gx, gv, h, ds, order=None):
@@ -140,29 +140,24 @@ class ShardedBackTracerC(torch.autograd.Function):
     """``BackTracerC`` (core/tracer.py:294-335) over this rank's ray shard; backward all-reduces
     dL/dn so every rank returns the gradient of the GLOBAL ray set.
 
-    ``apply(rif, x_local, v_local, h, ds, group=None, trace_fn=None, backtrace_fn=None)``
+    ``apply(rif, x_local, v_local, h, ds, group=None)``
 
-    ``trace_fn(rif_flat, shape, x, v, h, ds)`` returns ``(xt, vt)`` or ``(xt, vt, order)``; a non-None
-    ``order`` (the visit order the forward sorted this shard's rays into) is handed to
-    ``backtrace_fn(..., order=order)`` exactly as ``tracer.BackTracerC`` does on one GPU, so the sharded
-    adjoint runs the same fast path (no re-sort by exit rays)."""
+    The forward's visit order of the shard (and, riding on it, the per-ray iteration counts) is kept on ``ctx`` and
+    handed to the adjoint exactly as ``tracer.BackTracerC`` does on one GPU, so the sharded adjoint runs the same fast
+    path (no re-sort by exit rays).  The march is the HIP path (module functions ``_hip_trace`` / ``_hip_backtrace``;
+    the CPU tests replace those two names with stand-ins -- there is no injection hook in the product signature)."""
 
     @staticmethod
-    def forward(ctx, rif, x, v, h, ds, group=None,
-                trace_fn: Optional[Callable] = None, backtrace_fn: Optional[Callable] = None):
+    def forward(ctx, rif, x, v, h, ds, group=None):
         ctx.shape = rif.shape
         ctx.h, ctx.ds, ctx.group = h, ds, group
-        ctx.backtrace_fn = backtrace_fn or _hip_backtrace
-        out = (trace_fn or _hip_trace)(rif.detach().flatten(), ctx.shape, x.detach(), v.detach(), h, ds)
-        outx, outv = out[0], out[1]
-        ctx.order = out[2] if len(out) > 2 else None
+        outx, outv, ctx.order = _hip_trace(rif.detach().flatten(), ctx.shape, x.detach(), v.detach(), h, ds)
         ctx.save_for_backward(rif, outx, outv)          # version-checked: no silent use of a modified grid
         return outx, outv
 
     @staticmethod
     def backward(ctx, grad_x, grad_v):
         rif, outx, outv = ctx.saved_tensors
-        kw = {} if ctx.order is None else {"order": ctx.order}
-        drif = ctx.backtrace_fn(rif.detach().flatten(), ctx.shape, outx, outv, grad_x, grad_v, ctx.h, ctx.ds, **kw)
+        drif = _hip_backtrace(rif.detach().flatten(), ctx.shape, outx, outv, grad_x, grad_v, ctx.h, ctx.ds, order=ctx.order)
         drif = allreduce_grad(drif.reshape(*ctx.shape).contiguous(), ctx.group)
-        return drif, None, None, None, None, None, None, None
+        return drif, None, None, None, None, None

@@ -80,11 +80,14 @@ def using(**overrides):
 # last call's statistics (ray_steps, n_failed, iters) as a device tensor of 3 int64 words
 last_stats: Optional[torch.Tensor] = None
 
-# visit order (int32 ray indices) used by the last SORTED forward call -- a private copy, so it
-# survives later calls that reuse the workspace.  tracer.Back*TracerC keep it on ctx and hand it
-# to the paired backtrace (drrt_set_order_hint): the adjoint then visits rays in the forward's
-# bundle order (see include/drrt_hip.h, "visit order hand-over").
+# Visit order (int32 ray indices) used by the last SORTED forward call: a VIEW into that call's workspace, valid until
+# the next call on the same (device, stream) that sorts rays or stores state there -- any trace*, or a backtrace* that is
+# not given an order.  A stale view is recognised (generation stamp `drrt_gen`) and ignored by the calls it is handed
+# to, which then sort for themselves: slower, never wrong.  Holders that outlive the next call -- tracer.Back*TracerC's
+# ctx, dist.ShardedBackTracerC -- take a private copy with keep_order().  Handed to the paired backtrace
+# (drrt_set_order_hint) the adjoint visits rays in the forward's bundle order (include/drrt_hip.h, "visit order hand-over").
 last_order: Optional[torch.Tensor] = None
+_order_gen: Dict[tuple, int] = {}            # per workspace key: how often its order / state region has been rewritten
 
 # one scratch buffer per (device, stream): calls queued on different streams must not share scratch
 _workspaces: Dict[tuple, torch.Tensor] = {}
@@ -253,8 +256,15 @@ def read_stats(stats: Optional[torch.Tensor] = None) -> Dict[str, int]:
     return dict(ray_steps=int(s[0]), n_failed=int(s[1]), iters=int(s[2]) & 0xFFFFFFFF)
 
 
+def _bump_order_gen(device: torch.device) -> None:
+    """The call about to be made rewrites the order / state region of this (device, stream)'s workspace."""
+    k = _wkey(device)
+    _order_gen[k] = _order_gen.get(k, 0) + 1
+
+
 def _capture_order(n: int, device: torch.device) -> None:
-    """Copy the permutation the library just left in the workspace (device-to-device, async)."""
+    """Hand out the permutation (and the per-ray iteration counts) the library just left in the workspace: views, no
+    copies -- see `last_order`."""
     global last_order
     last_order = None
     if not _opt().sort_rays or n < 2:
@@ -263,17 +273,42 @@ def _capture_order(n: int, device: torch.device) -> None:
     ptr = _lib.load().drrt_last_order(C.byref(cnt))
     if not ptr or cnt.value != n:
         return
-    ws = _workspaces[_wkey(device)]
+    key = _wkey(device)
+    ws = _workspaces[key]
     off = int(ptr) - ws.data_ptr()
     if 0 <= off and off + 4 * n <= ws.numel():
-        last_order = ws[off:off + 4 * n].view(torch.int32).clone()
+        last_order = ws[off:off + 4 * n].view(torch.int32)
+        last_order.drrt_gen = (key, _order_gen.get(key, 0))
         # the forward march's per-ray iteration counts ride along ON the order tensor (attribute `drrt_steps`), so every
-        # holder of the order -- tracer.Back*TracerC's ctx, dist.ShardedBackTracerC -- hands both to the paired adjoint:
-        # its rays then start on the forward march's clock (step hint, include/drrt_hip.h)
+        # holder of the order hands both to the paired adjoint: its rays then start on the forward march's clock (step
+        # hint, include/drrt_hip.h)
         ptr_s = _lib.load().drrt_last_steps(C.byref(cnt))
         off_s = int(ptr_s) - ws.data_ptr() if ptr_s else -1
         if ptr_s and cnt.value == n and 0 <= off_s and off_s + 4 * n <= ws.numel():
-            last_order.drrt_steps = ws[off_s:off_s + 4 * n].view(torch.int32).clone()
+            last_order.drrt_steps = ws[off_s:off_s + 4 * n].view(torch.int32)
+
+
+def keep_order(order: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """A private copy of a visit order (with its iteration counts) that stays valid whatever is called next; None for a
+    stale or missing order.  For holders that keep the order across other tracer calls (autograd ctx)."""
+    order = _valid_order(order)
+    if order is None or getattr(order, "drrt_gen", None) is None:
+        return order
+    kept = order.clone()
+    steps = getattr(order, "drrt_steps", None)
+    if steps is not None:
+        kept.drrt_steps = steps.clone()
+    return kept
+
+
+def _valid_order(order: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """`order` unless it is a workspace view whose region has been rewritten since it was handed out."""
+    if order is None:
+        return None
+    gen = getattr(order, "drrt_gen", None)
+    if gen is not None and _order_gen.get(gen[0], 0) != gen[1]:
+        return None
+    return order
 
 
 last_bundle_counters: Optional[torch.Tensor] = None
@@ -293,21 +328,27 @@ def _capture_counters(ws: torch.Tensor) -> None:
 
 
 def read_bundle_counters() -> Optional[Dict[str, int]]:
-    """Synchronising read of `last_bundle_counters` -> which adjoint kernel the last backtrace* call chose, and why."""
+    """Synchronising read of `last_bundle_counters` -> which adjoint kernel the last backtrace* call chose, and why.
+    The rule is the library's own (`drrt_ring_threshold_pct()`: its compile-time threshold, so variant builds report
+    what they ran); the counters look at the bundles' START cells, before the step hint's delays."""
     if last_bundle_counters is None:
         return None
     c = [int(v) for v in last_bundle_counters.cpu()]
     share = c[0] / c[1] if c[1] else 0.0
+    pct = int(_lib.load().drrt_ring_threshold_pct())
     return dict(bundles_not_fitting=c[0], bundles=c[1], lanes_outside=c[2], lanes=c[3], not_fitting_share=share,
-                kernel="ring" if (c[0] and c[0] * 100 >= c[1] * 20) else "box")
+                ring_threshold_pct=pct, kernel="ring" if (c[0] and c[0] * 100 >= c[1] * pct) else "box")
 
 
-def _hint(order: Optional[torch.Tensor], n: int) -> None:
+def _hint(order: Optional[torch.Tensor], n: int) -> bool:
+    """Arm the library's order (and step) hint for the next march call; -> whether an order was handed over."""
     if order is not None and order.numel() == n and order.dtype == torch.int32 and order.is_cuda:
         _lib.load().drrt_set_order_hint(C.c_void_p(order.data_ptr()), n)
         steps = getattr(order, "drrt_steps", None)
         if steps is not None and steps.numel() == n and steps.dtype == torch.int32 and steps.device == order.device:
             _lib.load().drrt_set_step_hint(C.c_void_p(steps.data_ptr()), n)
+        return True
+    return False
 
 
 def _clear_hint() -> None:
@@ -398,6 +439,7 @@ class TracerC:
             fl = _flags() | (_lib.FLAG_Q16_POS_ONLY if qpos else 0)
             q16 = q16 or qpos
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev), _new_stats(dev)
+            _bump_order_gen(dev)
             fn = _lib.load().drrt_trace_q16io if q16 else (_lib.load().drrt_trace_f16io if half else _lib.load().drrt_trace_f32)
             _lib.check(fn(
                 _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), float(h), float(ds),
@@ -417,6 +459,7 @@ class TracerC:
             fm = torch.empty(n, dtype=torch.uint8, device=dev)
             fl = _flags()
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev), _new_stats(dev)
+            _bump_order_gen(dev)
             _lib.check(_lib.load().drrt_trace_pln_f32(
                 _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), _p(po), _p(pd),
                 float(h), float(ds), _p(xt), _p(vt), _p(fm), _p(st), _p(ws), ws.numel(), fl,
@@ -436,6 +479,7 @@ class TracerC:
             d2 = torch.empty(n, dtype=torch.float32, device=dev)
             fl = _flags()
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev), _new_stats(dev)
+            _bump_order_gen(dev)
             _lib.check(_lib.load().drrt_trace_target_f32(
                 _p(rif_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_), _p(tg),
                 float(h), float(ds), _p(xt), _p(vt), _p(d2), _p(st), _p(ws), ws.numel(), fl,
@@ -457,6 +501,7 @@ class TracerC:
             xt, vt = torch.empty_like(pos_), torch.empty_like(vel_)
             fl = _flags()
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev), _new_stats(dev)
+            _bump_order_gen(dev)
             _lib.check(_lib.load().drrt_trace_sdf_f32(
                 _p(rif_), _p(sdf_), rif_.numel(), _res3(res), n, _p(pos_), _p(vel_),
                 float(h), float(ds), _p(xt), _p(vt), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
@@ -486,6 +531,7 @@ class TracerC:
         float16 xt, vt, dx, dv select the fp16 ray-state variant (fp32 recurrences and accumulation)."""
         dev = _dev(rif)
         with torch.cuda.device(dev):
+            order = _valid_order(order)
             half = _is_half(xt, vt, dx, dv)
             q16 = _is_q16(xt, vt)                      # q16 exit rays + IEEE-half seeds (drrt_backtrace_q16io)
             qpos = (not q16) and xt.dtype == torch.int16           # q16 positions; directions and seeds fp32
@@ -501,7 +547,8 @@ class TracerC:
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None, adjoint=True), _new_stats(dev)
             fn = _lib.load().drrt_backtrace_q16io if q16 else (_lib.load().drrt_backtrace_f16io if half else _lib.load().drrt_backtrace_f32)
             try:
-                _hint(order, n)
+                if not _hint(order, n):
+                    _bump_order_gen(dev)               # the adjoint sorts for itself: it rewrites the order region
                 _lib.check(fn(
                     _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
                     float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
@@ -514,6 +561,7 @@ class TracerC:
         """Tracer::backtrace_sdf, src/tracer.cpp:443-509."""
         dev = _dev(rif)
         with torch.cuda.device(dev):
+            order = _valid_order(order)
             rif_, sdf_ = _f32(rif, dev).reshape(-1), _f32(sdf, dev).reshape(-1)
             if sdf_.numel() != rif_.numel():
                 raise RuntimeError("Resolution doesn't match data")
@@ -524,7 +572,8 @@ class TracerC:
             fl = _flags(adjoint=True)
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None, adjoint=True), _new_stats(dev)
             try:
-                _hint(order, n)
+                if not _hint(order, n):
+                    _bump_order_gen(dev)
                 _lib.check(_lib.load().drrt_backtrace_sdf_f32(
                     _p(rif_), _p(sdf_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
                     float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))

@@ -96,6 +96,9 @@ def _single_plane(*vecs) -> None:
     """The fused sensor operators take ONE plane / frame per call (the reference calls them once per view with (1, 3)
     tensors, core/image_opt.py:99-119).  A (N, 3) tensor whose rows differ -- per-ray planes -- would silently use row 0:
     refuse it (``trace_rays_to_plane`` is the operator that takes per-ray planes)."""
+    from .drrt import _capturing
+    if _capturing():               # the row comparison reads a device value on the host: not capturable; a captured call
+        return                     # has been checked when it ran eagerly before the capture
     for t in vecs:
         if isinstance(t, torch.Tensor) and t.dim() == 2 and t.shape[0] > 1 and not bool((t == t[:1]).all()):
             raise RuntimeError("this sensor operator takes one plane / frame per call (rows differ); split the rays by "

@@ -31,7 +31,8 @@ class BackTracerC(torch.autograd.Function):
         ctx.shape = rif.shape
         ctx.h, ctx.ds = h, ds
         outx, outv = drrt.TracerC().trace(rif.detach().flatten(), ctx.shape, x.detach(), v.detach(), h, ds)
-        ctx.order = drrt.last_order          # the adjoint visits rays in the forward's bundle order
+        ctx.order = drrt.keep_order(drrt.last_order)     # the adjoint visits rays in the forward's bundle order (a private
+        #                                                  copy: other tracer calls may come before backward)
         ctx.save_for_backward(rif, outx, outv)
         return outx, outv
 
@@ -52,7 +53,7 @@ class BackPlaneTracerC(torch.autograd.Function):
         ctx.h, ctx.ds = h, ds
         outx, outv, outmask = drrt.TracerC().trace_pln(
             rif.detach().flatten(), ctx.shape, x.detach(), v.detach(), sp.detach(), sn.detach(), h, ds)
-        ctx.order = drrt.last_order
+        ctx.order = drrt.keep_order(drrt.last_order)
         outmask = outmask.to(torch.bool)
         ctx.mark_non_differentiable(outmask)
         ctx.save_for_backward(rif, outx, outv)
@@ -78,7 +79,7 @@ class BackTargetTracerC(torch.autograd.Function):
         ctx.h, ctx.ds = h, ds
         outx, outv, dist2 = drrt.TracerC().trace_target(
             rif.detach().flatten(), ctx.shape, x.detach(), v.detach(), sp.detach(), h, ds)
-        ctx.order = drrt.last_order
+        ctx.order = drrt.keep_order(drrt.last_order)
         ctx.save_for_backward(rif, outx, outv)
         return outx, outv, dist2
 
@@ -99,7 +100,7 @@ class BackSDFTracerC(torch.autograd.Function):
         ctx.h, ctx.ds = h, ds
         outx, outv = drrt.TracerC().trace_sdf(rif.detach().flatten(), sdf.detach().flatten(), ctx.shape, x.detach(),
                                               v.detach(), h, ds)
-        ctx.order = drrt.last_order
+        ctx.order = drrt.keep_order(drrt.last_order)
         ctx.save_for_backward(rif, sdf, outx, outv)
         return outx, outv
 

@@ -86,16 +86,19 @@ def parse_args(argv=None):
     ap.add_argument("--fwd-flags", type=lambda v: int(v, 0), default=0, help="extra DRRT_FLAG_* bits for the forward call")
     ap.add_argument("--adj-flags", type=lambda v: int(v, 0), default=0, help="extra DRRT_FLAG_* bits for the adjoint call")
     ap.add_argument("--shard-of", type=int, default=0, metavar="G",
-                    help="single process: march only shard 0 of G of the strong-scaling ray set (what ONE rank of a G-GPU "
-                         "run does, without the all-reduce) -- per-shard timings for the scaling projection in DESIGN.md")
+                    help="single process: march only shard --shard-index of G of the strong-scaling ray set (what ONE rank of "
+                         "a G-GPU run does, without the all-reduce) -- per-shard timings for the scaling projection in "
+                         "DESIGN.md (tools/run_shards.sh times every index and takes the max)")
+    ap.add_argument("--shard-index", type=int, default=0, metavar="K", help="which shard of --shard-of (default 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the `variants` leg (the reference's six rotated views and the shifted plane source)")
     ap.add_argument("--variant-steps", type=int, default=5)
-    ap.add_argument("--variants", default="cube6_rotated,plane_shifted", help="comma list of the variants to run")
-    ap.add_argument("--workload", choices=("metric", "cube6_rotated", "plane_shifted"), default="metric",
-                    help="ray set of the MAIN run (default: the metric's plane source).  The other two are the `variants` ray "
-                         "sets run as the main workload -- for profiling them on their own (1 GPU)")
+    ap.add_argument("--variants", default="cube6_rotated,plane_shifted,tomo_weak", help="comma list of the variants to run")
+    ap.add_argument("--workload", choices=("metric", "cube6_rotated", "plane_shifted", "tomo_weak"), default="metric",
+                    help="ray set (and medium) of the MAIN run (default: the metric's plane source through the Luneburg ball).  "
+                         "The others are the `variants` run as the main workload -- for profiling them on their own and for "
+                         "their shard timings / multi-GPU runs (multi-view sets are sharded view by view, dist.shard_views)")
     ap.add_argument("--source-axis", choices=("x", "y", "z"), default="y",
                     help="A-B: the metric's plane source on the x=0 / z=0 face instead of y=0 (rays along that axis; the ball is "
                          "symmetric, so the work is the same and only the memory order of the cells along the rays differs)")
@@ -104,6 +107,8 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.shard_of and not (0 <= args.shard_index < args.shard_of):
+        ap.error("--shard-index must lie in [0, --shard-of)")
     if args.scaling is None:
         args.scaling = "strong" if args.gpus == 1 else "both"
     return args
@@ -166,6 +171,30 @@ def make_grid(R: int, device):
     Z, Y, X = torch.meshgrid(g, g, g, indexing="ij")
     r = torch.sqrt((X - span / 2) ** 2 + (Y - span / 2) ** 2 + (Z - span / 2) ** 2) / (span / 2)
     return torch.sqrt(2.0 - torch.clamp(r, max=1.0) ** 2).to(torch.float32).contiguous()
+
+
+def make_grid_tomo(R: int, device, seed: int = 0):
+    """SURVEY 8.6's second medium, the weak-deflection regime of the tomography experiment (value range of
+    data/fuel_injection_64.npy, core/fuel_injection_opt.py:41-43): n = 1 + 3e-4 U, U = torch.rand (seed 0) low-pass
+    filtered (three passes of a 9^3 box filter = a smooth kernel ~16 voxels wide) and rescaled to [0, 1]."""
+    import torch
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    u = torch.rand(R, R, R, generator=gen).to(device)[None, None]
+    for _ in range(3):
+        u = torch.nn.functional.avg_pool3d(torch.nn.functional.pad(u, (4,) * 6, mode="replicate"), 9, stride=1)
+    u = u[0, 0]
+    u = (u - u.min()) / (u.max() - u.min())
+    return (1.0 + 3e-4 * u).to(torch.float32).contiguous()
+
+
+def truncated_views(rays_per_view, n):
+    """Per-view ray counts of the first n rays of a multi-view set (the last views lose what the truncation removes)."""
+    out, left = [], n
+    for c in rays_per_view:
+        k = min(int(c), left)
+        out.append(k)
+        left -= k
+    return out
 
 
 def make_rays(n_rays: int, seed: int):
@@ -432,7 +461,9 @@ def run_rank(args) -> int:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def bench_rays(pos, vel, steps, warmup, force_flags=None, keep=False):
+    ring_pct = int(lib.drrt_ring_threshold_pct())
+
+    def bench_rays(pos, vel, steps, warmup, force_flags=None, keep=False, rif=rif):
         """Time `steps` fwd + adjoint passes over the rays (pos, vel) resident on the device; -> this rank's measurements.
         force_flags = (fflags, aflags, pair) overrides the pair-copy rule (parity runs on a sub-sample keep the flags)."""
         n = pos.shape[0]
@@ -487,6 +518,16 @@ def run_rank(args) -> int:
                           dbg[19 + 4 * k], dbg[20 + 4 * k]) for k in range(11)]), file=sys.stderr)
         fwd_steps = int(st_f[0].item()); adj_steps = int(st_a[0].item())
         n_failed = int(st_f[1].item())
+        # which adjoint kernel the device-side bundle classification of the LAST step chose (drrt_last_bundle_counters)
+        choice = None
+        cptr = lib.drrt_last_bundle_counters()
+        if cptr:
+            off = int(cptr) - ws.data_ptr()
+            if 0 <= off and off + 16 <= ws.numel():
+                c = ws[off:off + 16].view(torch.int32).cpu().tolist()
+                choice = {"kernel": "ring" if (c[0] and c[0] * 100 >= c[1] * ring_pct) else "box",
+                          "bundles_not_fitting": c[0], "bundles_sampled": c[1], "ring_threshold_pct": ring_pct,
+                          "lanes_far_from_bundle": c[2], "lanes_sampled": c[3]}
         t = torch.tensor([elapsed, float(fwd_steps), float(adj_steps)], dtype=torch.float64, device=dev)
         if use_dist:
             tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -501,13 +542,13 @@ def run_rank(args) -> int:
         out = dict(n=n, steps=steps, elapsed=elapsed, fwd_total=fwd_total, adj_total=adj_total, fwd_steps=fwd_steps,
                    adj_steps=adj_steps, n_failed=n_failed, ms_fwd=avg("trace"), ms_adj=avg("backtrace"),
                    ms_sort=avg("sort"), ms_zero=avg("zero"), ms_quad=avg("quad"), ms_allreduce=ms_ar, pair=pair,
-                   pos=pos, vel=vel, flags=(fflags, aflags, pair), dbg=dbg)
+                   pos=pos, vel=vel, flags=(fflags, aflags, pair), dbg=dbg, adjoint_kernel=choice)
         if keep:                                   # results of the LAST step (the adjoint's grid holds this rank's gradient
             out.update(xt=xt, vt=vt,               # only when there is no all-reduce: parity_check runs at world == 1)
                        grad=grad.clone())
         return out
 
-    def direct_atomics_grad(m):
+    def direct_atomics_grad(m, rif=rif):
         """dL/dn of the rays of measurement `m` (its exit rays `xt`, `vt`, dx = dv = 1) by the one-atomic-per-tap kernel:
         no windows, no register accumulators, no visit order -- the in-library cross-check of the windowed adjoint."""
         n = m["pos"].shape[0]
@@ -521,44 +562,65 @@ def run_rank(args) -> int:
     def rel_l2(a, b):
         return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
 
-    def run_mode(mode):
-        """-> dict of this rank's measurements for one scaling mode."""
-        if args.workload != "metric":                              # a variant's ray set as the main run (profiling aid)
-            assert world == 1, "--workload other than metric: one GPU"
-            if args.workload == "plane_shifted":
-                pos, vel = (t.to(dev) for t in make_rays_shifted(args.rays, seed=0))
-            else:
-                pos, vel, _ = make_rays_cube6(args.rays, 0, dev)
-            out = bench_rays(pos, vel, args.steps, args.warmup, keep=False)
-            out["mode"] = mode
-            return out
-        if mode == "strong":
-            gpos, gvel = make_rays(args.rays, seed=0)              # the metric's single ray set, same on every rank
+    grids = {}
+
+    def workload_set(name, n_rays, seed):
+        """-> (grid, pos, vel, per-view ray counts or None, description) of a named workload, rays resident on the device."""
+        if name == "metric":
+            gpos, gvel = make_rays(n_rays, seed=seed)
             if args.source_axis != "y":                            # A-B: the same source on another face (the ball is symmetric)
                 perm = {"x": [1, 0, 2], "z": [0, 2, 1]}[args.source_axis]
                 gpos, gvel = gpos[:, perm].contiguous(), gvel[:, perm].contiguous()
-            lo, hi = drrt_dist.shard_bounds(args.rays, rank, world)
+            return rif, gpos.to(dev), gvel.to(dev), None, {}
+        if name == "plane_shifted":
+            gpos, gvel = make_rays_shifted(n_rays, seed=seed)
+            return rif, gpos.to(dev), gvel.to(dev), None, {"rays": "the headline's plane source moved by 1/3 pixel in x and z"}
+        gpos, gvel, info = make_rays_cube6(n_rays, seed, dev)
+        views = truncated_views(info["rays_per_view"], n_rays)
+        meta = {"rays": "source.rand_rays_cube((P, P), 1, span, circle=True) + random_rotate_ic "
+                        "(core/source.py:398-412,555-563; core/luneburg_opt.py:53-57), device generators, first "
+                        f"{n_rays} rays", **info}
+        if name == "tomo_weak":
+            if "tomo" not in grids:
+                grids["tomo"] = make_grid_tomo(R, dev)
+            meta["medium"] = ("n = 1 + 3e-4 U, U = low-pass filtered torch.rand (seed 0) rescaled to [0, 1]: the weak-deflection "
+                              "regime of core/fuel_injection_opt.py:41-43 (SURVEY 8.6, second medium)")
+            return grids["tomo"], gpos, gvel, views, meta
+        return rif, gpos, gvel, views, meta
+
+    def shard_of_set(pos, vel, views, k, G):
+        """Shard k of G: one contiguous piece of a single-view set, a strip of EVERY view of a multi-view set."""
+        if G <= 1:
+            return pos, vel
+        if views is None:
+            lo, hi = drrt_dist.shard_bounds(pos.shape[0], k, G)
+            return pos[lo:hi].contiguous(), vel[lo:hi].contiguous()
+        spans = drrt_dist.shard_views(views, k, G)
+        return (torch.cat([pos[lo:hi] for lo, hi in spans]).contiguous(),
+                torch.cat([vel[lo:hi] for lo, hi in spans]).contiguous())
+
+    def run_mode(mode):
+        """-> dict of this rank's measurements for one scaling mode."""
+        if mode == "strong":
+            g, gpos, gvel, views, _ = workload_set(args.workload, args.rays, 0)     # ONE global ray set, same on every rank
             if args.shard_of > 1 and world == 1:
-                lo, hi = drrt_dist.shard_bounds(args.rays, 0, args.shard_of)
-            pos, vel = gpos[lo:hi].contiguous().to(dev), gvel[lo:hi].contiguous().to(dev)
+                pos, vel = shard_of_set(gpos, gvel, views, args.shard_index, args.shard_of)
+            else:
+                pos, vel = shard_of_set(gpos, gvel, views, rank, world)
         else:
-            pos, vel = (t.to(dev) for t in make_rays(args.rays, seed=rank))
-        out = bench_rays(pos, vel, args.steps, args.warmup, keep=(world == 1 and mode == "strong"))
+            g, pos, vel, views, _ = workload_set(args.workload, args.rays, rank)
+        out = bench_rays(pos, vel, args.steps, args.warmup,
+                         keep=(world == 1 and mode == "strong" and args.workload == "metric"), rif=g)
         out["mode"] = mode
+        out["multi_view"] = views is not None
         return out
 
     def run_variant(name):
-        """The other ray distributions of SURVEY 8.6 on the same grid (1 GPU; after the headline run, not part of `value`)."""
-        if name == "plane_shifted":
-            pos, vel = (t.to(dev) for t in make_rays_shifted(args.rays, seed=0))
-            meta = {"rays": "the headline's plane source moved by 1/3 pixel in x and z"}
-        else:
-            pos, vel, info = make_rays_cube6(args.rays, 0, dev)
-            meta = {"rays": "source.rand_rays_cube((P, P), 1, span, circle=True) + random_rotate_ic "
-                            "(core/source.py:398-412,555-563; core/luneburg_opt.py:53-57), device generators, first "
-                            f"{args.rays} rays", **info}
-        v = bench_rays(pos, vel, args.variant_steps, 2, keep=True)
-        g_ref = direct_atomics_grad(v)
+        """The other ray distributions / media of SURVEY 8.6 on the same grid size (1 GPU; after the headline run, not part
+        of `value`)."""
+        g, pos, vel, views, meta = workload_set(name, args.rays, 0)
+        v = bench_rays(pos, vel, args.variant_steps, 2, keep=True, rif=g)
+        g_ref = direct_atomics_grad(v, rif=g)
         fl = v["flags"]
         res_ = {"n_rays": v["n"], "steps": v["steps"], "ms_per_step": v["elapsed"] / v["steps"] * 1e3,
                 "trace": v["ms_fwd"], "backtrace": v["ms_adj"], "sort": v["ms_sort"],
@@ -566,10 +628,12 @@ def run_rank(args) -> int:
                 "value": v["fwd_steps"] * v["steps"] / v["elapsed"],
                 "fwd_ns_per_ray_step": v["ms_fwd"] * 1e6 / max(v["fwd_steps"], 1),
                 "adj_ns_per_ray_step": v["ms_adj"] * 1e6 / max(v["adj_steps"], 1),
-                "pair_grid": bool(fl[2]), "grad_rel_l2_vs_direct_atomics": rel_l2(v["grad"], g_ref)}
+                "pair_grid": bool(fl[2]), "adjoint_kernel": v["adjoint_kernel"],
+                "grad_rel_l2_vs_direct_atomics": rel_l2(v["grad"], g_ref)}
         res_.update(meta)
         return res_
 
+    rc = 0
     modes = ["strong", "weak"] if args.scaling == "both" else [args.scaling]
     results = {m: run_mode(m) for m in modes}
     main_mode = modes[0]
@@ -600,8 +664,12 @@ def run_rank(args) -> int:
                     f"measured in this run") if pmc_src else None
         shard = (f"the metric's single set of {args.rays} rays split into {world} contiguous shards "
                  f"({n} on rank 0)") if main_mode == "strong" else f"{n} rays per GPU (own seed per rank)"
+        if args.shard_of > 1 and world == 1:
+            shard += f"; THIS RUN: shard {args.shard_index} of {args.shard_of} only"
         if args.workload != "metric":
-            shard = f"NOT the metric's source: the `{args.workload}` ray set of `variants` ({n} rays)"
+            shard = (f"NOT the metric's source: the `{args.workload}` workload of `variants` ({n} rays on rank 0"
+                     + (", a strip of every view per rank" if m.get("multi_view") else "") + ")"
+                     + (f"; THIS RUN: shard {args.shard_index} of {args.shard_of} only" if args.shard_of > 1 and world == 1 else ""))
         roof = {"bound": "hbm", "kernel": "adjoint march (k_backtrace_flat)", "achieved": ach_adj,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_adj / HBM_PEAK_GBS, "traffic": tr_adj,
                 "traffic_source": src_note, "pmc_source": pmc_src, "pmc_lib_version": pmc_lib, "pmc_stale": pmc_stale,
@@ -632,7 +700,8 @@ def run_rank(args) -> int:
                        "fwd_ray_steps_global": m["fwd_total"], "n_failed": m["n_failed"],
                        "sort_rays": not args.no_sort, "pair_grid": bool(m["pair"]),
                        "parallelism": f"ray-shard x{world}", "backend": args.backend if use_dist else None,
-                       "shard_of": args.shard_of or None},
+                       "shard_of": args.shard_of or None, "shard_index": args.shard_index if args.shard_of else None,
+                       "adjoint_kernel": m["adjoint_kernel"]},
             "roofline": roof,
             "roofline_fwd": roof_f,
             "phase_ms": {"sort_avg": m["ms_sort"], "zero_grid": m["ms_zero"],
@@ -678,14 +747,19 @@ def run_rank(args) -> int:
             if parity is not None:
                 out["parity_check"] = parity
                 if not parity["ok"]:
+                    # a number whose kernels disagree with the oracle is not a result: no `value`, non-zero exit
                     print("bench.py: PARITY CHECK FAILED: " + json.dumps(parity), file=sys.stderr)
+                    out = {"metric": out["metric"], "value": None, "unit": out["unit"], "n_gpus": world,
+                           "error": "parity_check failed: the timed kernels disagree with the oracle; no throughput is reported",
+                           "lib_version": lib_version, "parity_check": parity}
+                    rc = 3
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if use_dist:
         dist.destroy_process_group()
-    return 0
+    return rc
 
 
 def main():

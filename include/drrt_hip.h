@@ -173,8 +173,11 @@ DRRT_API void drrt_set_step_hint(const uint32_t* steps, size_t n);
  * order, a forced kernel, a workspace without the counter block).  Over every 16th block of 64-ray bundles:
  *   [0] bundles whose start cells do not fit the box window, [1] bundles looked at,
  *   [2] lanes whose start cell lies more than 3 cells from their bundle's mean cell, [3] lanes looked at (diagnostic).
- * The ring-window kernel runs when [0] / [1] >= 20 % (calibration: csrc/drrt_kernels.hip, k_bundle_classify). */
+ * The ring-window kernel runs when [0] * 100 >= [1] * drrt_ring_threshold_pct() (the library's compile-time threshold, 20 in
+ * the product build; calibration: csrc/drrt_march.h, bundles_want_ring).  The counters describe the START cells of the
+ * bundles (the exit rays as given), not where the step hint's delays put the lanes later on. */
 DRRT_API const unsigned* drrt_last_bundle_counters(void);
+DRRT_API int drrt_ring_threshold_pct(void);
 
 /* ---- 16-bit ray state "q16" (BASELINE.json config 5: "fp16 ray state + fp32 adjoint accumulate") -----------------
  * The reference is fp32-only (include/types.h:36-46).  IEEE half keeps 11 significant bits wherever the value is:

@@ -211,12 +211,21 @@ def test_config4_image_caustic_fp16_rays_512_sensor(gpu, D):
         assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
         grads[mode] = (g, float(loss.detach()))
     assert abs(grads["f16"][1] - grads["f32"][1]) <= 2e-2 * abs(grads["f32"][1])
-    # Storing the exit rays in fp16 quantises positions near 1.0 to 2^-11 = 1/8 voxel (1/4 sensor pixel) and
-    # the seeds to 11 bits: measured 0.26 rel-L2 between the two gradients on this configuration -- a
-    # property of the storage format (the f16io kernels equal the f32 kernels on widened inputs bit for bit,
-    # test_fp16_ray_state_mode).  The descent direction is preserved:
+    # The IEEE-half ray state is KEPT FOR A/B ONLY (the 16-bit mode to use is q16, next test): storing the exit rays in
+    # fp16 quantises positions near 1.0 to 2^-11 = 1/8 voxel (1/4 sensor pixel) and the seeds to 11 bits, and the
+    # discontinuous gradient splat turns a perturbation of d voxels into ~sqrt(d) rel-L2 between two sparse gradient grids.
+    # What is asserted is that measured loss of the format, raw and at the 3-voxel scale an optimiser sees -- the same two
+    # comparisons as the q16 test, with the bounds this format can meet (raw: measured 0.26; q16: 0.055 / 0.013).  The
+    # kernels themselves equal the f32 kernels on widened inputs bit for bit (test_fp16_ray_state_mode).
     a, b = grads["f16"][0].double().flatten(), grads["f32"][0].double().flatten()
-    assert float((a @ b) / (a.norm() * b.norm())) >= 0.9
+    raw = float((a - b).norm() / b.norm())
+
+    def smooth(g):
+        return torch.nn.functional.avg_pool3d(g.reshape(1, 1, *rif.shape).double(), 3, stride=1, padding=1).flatten()
+    sa, sb = smooth(grads["f16"][0]), smooth(grads["f32"][0])
+    filt = float((sa - sb).norm() / sb.norm())
+    print(f"IEEE-half ray state vs fp32 ray state: gradient rel-L2 raw {raw:.3e}, 3^3-filtered {filt:.3e}")
+    assert raw <= 0.35 and filt <= raw
 
 
 def test_config4_q16_ray_state_keeps_the_gradient(gpu, D):
@@ -414,7 +423,7 @@ def test_config1_adjoint_vs_fp64_on_tie_free_rays(gpu, oracle, D):
         lies EXACTLY on a y-face of a cell, so most rays have tie events (reported), and the tie-free rest contains
         rays grazing the lens edge -- a kink of the index profile with mixed partials ~1/h -- along which a 1e-7
         rounding difference grows exponentially (measured on the oracle: 3 of 500 rays carry 99.9 % of the error).
-        There the bar is: within 1e-3 of fp64, and >= 10x closer to fp64 than the reference's OWN expression order
+        There the bar is: within 2.5e-4 of fp64 (measured 1.25e-4), and >= 10x closer to fp64 than the reference's OWN expression order
         evaluated in fp32 (literal f32 oracle), i.e. closer to the exact adjoint than any fp32 build of the reference.
     The measured numbers are printed and written to gpurun_out/tie_report.json (DESIGN.md section 3 quotes them)."""
     import json, os
@@ -456,7 +465,8 @@ def test_config1_adjoint_vs_fp64_on_tie_free_rays(gpu, oracle, D):
     pos = rng.uniform(0, span * (1 - 1e-6), (n, 3)).astype(np.float32); pos[:, 1] = 0.0
     vel = np.tile(np.array([[0, 1, 0]], np.float32), (n, 1))
     b = study("config1_luneburg_128_plane", cases.luneburg(R, span), pos, vel)
-    assert b["hip_tiefree_vs_f64"] <= 1e-3                         # measured 3e-4 (lens-edge grazing rays)
+    assert b["hip_tiefree_vs_f64"] <= 2.5e-4                       # measured 1.25e-4, rounds 2 and 4 (lens-edge grazing rays);
+    #                                                                 # north_star's 1e-4 is NOT met on this degenerate configuration
     assert b["hip_tiefree_vs_f64"] * 10 <= b["literal_f32_tiefree_vs_f64"]
     assert b["hip_all_vs_f64"] <= 5e-2
     os.makedirs("gpurun_out", exist_ok=True)
@@ -500,35 +510,30 @@ def test_metric_workload_runs_on_the_fast_kernels(gpu, D):
     assert prof.get("backtrace", 1e9) < 15.0, prof       # measured 4.85 ms
 
 
-@pytest.mark.parametrize("workload", ["metric", "cube6_rotated"])
+@pytest.mark.parametrize("workload", ["metric", "cube6_rotated", "tomo_weak"])
 def test_bench_workloads_against_the_oracle_at_full_size(gpu, oracle, D, workload):
-    """The two ray sets bench.py times -- the metric's plane source and the reference's six randomly rotated views
-    (core/source.py:398-412,555-563) -- through the drop-in API exactly as the benchmark runs them (sort, pair copy by
-    rule, the forward's order and iteration counts handed to the adjoint, device-side choice of the adjoint kernel: box
-    window for the first, ring window for the second), ALL 1 048 576 rays against the all-cores oracle in the kernels'
-    arithmetic: exit rays bit-exact, step totals equal, rel-L2(dL/dn) <= 2e-5 (src/tracer.cpp:35-100,384-440)."""
+    """The ray sets / media bench.py times -- the metric's plane source, the reference's six randomly rotated views
+    (core/source.py:398-412,555-563) through the Luneburg ball, and the same views through the weak-deflection medium of
+    SURVEY 8.6 (core/fuel_injection_opt.py:41-43) -- through the drop-in API exactly as the benchmark runs them (sort,
+    pair copy by rule, the forward's order and iteration counts handed to the adjoint, device-side choice of the adjoint
+    kernel), ALL 1 048 576 rays against the all-cores oracle in the kernels' arithmetic: exit rays bit-exact, step totals
+    equal, rel-L2(dL/dn) <= 2e-5 (src/tracer.cpp:35-100,384-440).  The kernel the classification chose is asserted
+    (round-3 advisor: a drifting threshold or sort key would otherwise send a set to the slower kernel with every test
+    still green): box window for the metric's compact bundles, ring window for the rotated views."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     R, n = 256, 1 << 20
     span = 1.0; h = span / (R - 1); ds = h / 2
-    rif = bench.make_grid(R, gpu)
+    rif = bench.make_grid_tomo(R, gpu) if workload == "tomo_weak" else bench.make_grid(R, gpu)
     if workload == "metric":
         pos, vel = (t.to(gpu) for t in bench.make_rays(n, seed=0))
     else:
         pos, vel, _ = bench.make_rays_cube6(n, 0, gpu)
     T = D.TracerC()
-    res = (R, R, R)
-    xt, vt = T.trace(rif.reshape(-1), res, pos, vel, h, ds)
-    fwd = D.read_stats()
-    order = D.last_order
-    assert order is not None and getattr(order, "drrt_steps", None) is not None
-    ones = torch.ones_like(xt)
-    g = T.backtrace(rif.reshape(-1), res, xt, vt, ones, ones, h, ds, order=order)
-    adj = D.read_stats()
-    threads = max(1, min(len(os.sched_getaffinity(0)), 32))
-    with oracle.arith("factored"):
-        o = oracle.bench_allcores(rif.cpu().numpy(), res, pos.cpu().numpy(), vel.cpu().numpy(), h, ds, threads, want_rays=True)
-    assert np.array_equal(xt.cpu().numpy(), o["xt"]) and np.array_equal(vt.cpu().numpy(), o["vt"])
-    assert fwd["ray_steps"] == o["fwd_steps"] and adj["ray_steps"] == o["adj_steps"]
-    assert cases.rel_l2(g.cpu().numpy(), o["grad"]) <= 2e-5
+    _adjoint_vs_allcores_oracle(D, oracle, T, rif.reshape(-1), (R, R, R), pos, vel, h, ds)
+    c = D.read_bundle_counters()
+    print(workload, c)
+    assert c is not None
+    if workload != "tomo_weak":           # (the weak medium's straight rays sit between the two regimes: either kernel is right)
+        assert c["kernel"] == ("box" if workload == "metric" else "ring"), c

@@ -1,6 +1,6 @@
 """CPU tier: the ray-sharded multi-process path (adjointnonlinearraytracing_amd/dist.py) with
-world_size 2 over gloo.  The per-rank march is injected (the CPU oracle stands in for the HIP
-kernels, which need a GPU); what is under test is the sharding, the hand-over of the forward's visit
+world_size 2 over gloo.  In the worker processes the two module functions of dist.py that call the HIP march are
+replaced by the CPU oracle (the kernels need a GPU); what is under test is the sharding, the hand-over of the forward's visit
 order to the adjoint, and the single all-reduce: every rank must end up with the gradient of the GLOBAL
 ray set."""
 import os
@@ -55,7 +55,8 @@ def _worker(rank, world, port, out_dir):
     pos, vel = cases.cube_rays(101, span, ds, seed=2)          # 606 rays: not divisible by 4
     pos, vel = torch.from_numpy(pos), torch.from_numpy(vel)
     x, v = D.shard_rays(rank, world, pos, vel)
-    xt, vt = D.ShardedBackTracerC.apply(rif, x, v, h, ds, None, _oracle_trace, _oracle_backtrace)
+    D._hip_trace, D._hip_backtrace = _oracle_trace, _oracle_backtrace      # this worker process only: the CPU stand-ins
+    xt, vt = D.ShardedBackTracerC.apply(rif, x, v, h, ds, None)
     loss = (xt ** 2).sum() + vt.sum()                          # ray-separable loss (core/luneburg_opt.py:102)
     loss.backward()
     assert len(_seen_orders) == 1 and _seen_orders[0].numel() == x.shape[0]     # the adjoint got this shard's order
@@ -157,7 +158,8 @@ def _image_worker(rank, world, port, out_dir):
     x, v = D.shard_rays(rank, world, pos, vel, views=views)               # a strip of EVERY view on every rank
     counts = D.local_views(n, views, rank, world)
     assert sum(counts) == x.shape[0] and min(counts) > 0
-    xt, vt = D.ShardedBackTracerC.apply(rif, x, v, h, ds, None, _oracle_trace, _oracle_backtrace)
+    D._hip_trace, D._hip_backtrace = _oracle_trace, _oracle_backtrace      # this worker process only: the CPU stand-ins
+    xt, vt = D.ShardedBackTracerC.apply(rif, x, v, h, ds, None)
     loss = _image_loss(xt, vt, counts, planes, targets, D.allreduce_image)
     loss.backward()
     np.save(os.path.join(out_dir, f"igrad_{rank}.npy"), rif.grad.numpy())

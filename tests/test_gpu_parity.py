@@ -132,7 +132,7 @@ def test_quad_grid_copy_is_bit_identical(gpu, oracle, drrt_mod, sort):
             for quad in (True, False):
                 drrt_mod.options.quad_grid = quad
                 xt, vt = T.trace(rif, res, P, V_, h, ds)
-                st, order = drrt_mod.read_stats(), drrt_mod.last_order
+                st, order = drrt_mod.read_stats(), drrt_mod.keep_order(drrt_mod.last_order)   # held across other trace calls
                 g_paired = T.backtrace(rif, res, xt, vt, DX, DV, h, ds, order=order)          # reuses the copy
                 xo, vo = T.trace(other, res, P, V_, h, ds)                                    # another grid in between
                 g_after = T.backtrace(rif, res, xt, vt, DX, DV, h, ds, order=order)           # must rebuild
@@ -485,7 +485,7 @@ def test_full_size_properties(gpu, drrt_mod):
     drrt_mod.options.sort_rays = True
     xt, vt = T.trace(rif, rif.shape, pos, vel, h, ds)
     st = drrt_mod.read_stats()
-    order = drrt_mod.last_order
+    order = drrt_mod.keep_order(drrt_mod.last_order)          # held across the two marches below
     # straight corner rays take 510-511 steps, rays through the ball (|v| = n > 1) fewer
     assert st["n_failed"] == 0 and 470 * n <= st["ray_steps"] <= 515 * n and 505 <= st["iters"] < 2048
     xt2, vt2 = T.trace(rif, rif.shape, pos, vel, h, ds)
@@ -636,6 +636,40 @@ def test_order_hint_lifetime_and_range_check(gpu, drrt_mod):
     assert all(torch.equal(u, w) for u, w in zip(a, b))
 
 
+def test_last_order_is_a_view_and_a_stale_one_is_ignored(gpu, oracle, drrt_mod):
+    """drrt.last_order is a view into the forward call's workspace (no device-to-device copy per call, round-3 review):
+    handed straight to the paired adjoint it is used as is; once another march has rewritten that workspace region the
+    view is recognised as stale and the adjoint sorts for itself -- same gradient, never a wrong visit order;
+    keep_order() gives a private copy that stays valid."""
+    R, span = 33, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif_np = cases.smooth_field(R, seed=2)
+    rif = _t(rif_np, gpu)
+    pos, vel = cases.cube_rays(700, span, ds, seed=3, tilt=0.2)
+    pos_o, vel_o = cases.cube_rays(700, span, ds, seed=4, tilt=0.2)
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = True
+    xt, vt = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+    view = drrt_mod.last_order
+    ws = drrt_mod._workspaces[drrt_mod._wkey(rif.device)]
+    assert view is not None and ws.data_ptr() <= view.data_ptr() < ws.data_ptr() + ws.numel()       # no copy was made
+    assert drrt_mod._valid_order(view) is view and getattr(view, "drrt_steps", None) is not None
+    kept = drrt_mod.keep_order(view)
+    assert kept.data_ptr() != view.data_ptr() and torch.equal(kept, view) and torch.equal(kept.drrt_steps, view.drrt_steps)
+    ones = torch.ones_like(xt)
+    g_view = T.backtrace(rif, rif.shape, xt, vt, ones, ones, h, ds, order=view)
+    assert drrt_mod._valid_order(view) is view                      # an adjoint that was handed the order does not rewrite it
+    T.trace(rif, rif.shape, _t(pos_o, gpu), _t(vel_o, gpu), h, ds)  # another march: the region now holds ITS order
+    assert drrt_mod._valid_order(view) is None and drrt_mod.keep_order(view) is None
+    g_stale = T.backtrace(rif, rif.shape, xt, vt, ones, ones, h, ds, order=view)
+    g_kept = T.backtrace(rif, rif.shape, xt, vt, ones, ones, h, ds, order=kept)
+    with oracle.arith("factored"):
+        ob = oracle.backtrace(rif_np, rif_np.shape, xt.cpu().numpy(), vt.cpu().numpy(), np.ones_like(pos), np.ones_like(pos),
+                              h, ds, dtype=np.float32)
+    for g in (g_view, g_stale, g_kept):
+        assert cases.rel_l2(g.cpu().numpy(), ob["grad"]) <= 2e-5
+
+
 def test_plane_second_pass_on_plain_grid_and_pair_copy(gpu, oracle, drrt_mod):
     """trace_pln must flag the rays that can record a LATER exit (start past the plane, head back through it) so
     that the second pass re-marches them: both gather forms of k_trace_flat<., 1> against the oracle on such rays."""
@@ -745,6 +779,58 @@ def test_adjoint_kernel_variants_agree(gpu, oracle, drrt_mod, kind, R, step_res)
         assert cases.rel_l2(g, base) <= 2e-5, k
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_ring_window_with_rays_that_run_out_of_steps_beside_delayed_lanes(gpu, oracle, drrt_mod, seed):
+    """Round-3 advisor finding: in k_backtrace_ring a ray that uses up its max_steps iterations while other lanes of its
+    wave are still marching (step hint: lanes start up to 96 iterations apart) hands its cell over on its own; the flag
+    that guards the wave's cooperative flushes must be wave-uniform again before the service of that same iteration.
+    Slow rays (they never leave the volume, so they DO run out of steps) mixed into the waves of ordinary rays, ds << h
+    so that windows stay clean for long stretches, arbitrary per-ray delays, ring kernel forced: step totals equal the
+    oracle's and the gradient is within the summation-order bound; equal to the box kernel's and the direct kernel's."""
+    import ctypes as C
+    from adjointnonlinearraytracing_amd import _lib
+    lib = _lib.load()
+    R, span = 33, 1.0
+    h = span / (R - 1); ds = h / 6
+    rif_np = cases.smooth_field(R, seed=11)
+    rng = np.random.default_rng(40 + seed)
+    n = 4096
+    xt = (rng.uniform(0.15, 0.85, (n, 3)) * span).astype(np.float32)
+    vt = rng.normal(size=(n, 3)).astype(np.float32)
+    vt /= np.linalg.norm(vt, axis=1, keepdims=True)
+    slow = rng.random(n) < 0.3
+    vt[slow] *= 0.002                                  # max_steps * ds * |v| << span: these rays end by running out of steps
+    dx = rng.normal(size=(n, 3)).astype(np.float32); dv = rng.normal(size=(n, 3)).astype(np.float32)
+    with oracle.arith("factored"):
+        ob = oracle.backtrace(rif_np, rif_np.shape, xt, vt, dx, dv, h, ds, dtype=np.float32)
+    max_steps = int(np.float32(2.0) * np.float32(h) * np.float32(R) / np.float32(ds))
+    assert ob["steps_total"] >= int(slow.sum()) * max_steps          # the slow rays really use all their iterations
+    res = (C.c_int * 3)(R, R, R)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rif = _t(rif_np, gpu).reshape(-1).contiguous()
+    xt_d, vt_d, dx_d, dv_d = (_t(a, gpu) for a in (xt, vt, dx, dv))
+    order = torch.arange(n, dtype=torch.int32, device=gpu)           # caller order: slow and ordinary rays share waves
+    fsteps = _t(rng.integers(0, 300, n).astype(np.int32), gpu)       # arbitrary "forward iteration counts" -> delays 0..96
+    grads = {}
+    for name, fl, hint in (("ring+steps", _lib.FLAG_RING_WINDOW, True), ("ring", _lib.FLAG_RING_WINDOW, False),
+                           ("box", _lib.FLAG_STATIC_WINDOW, False), ("direct", _lib.FLAG_DIRECT_ATOMICS, False)):
+        flags = fl | _lib.FLAG_SORT_RAYS
+        ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, rif.numel(), flags)) + 1024, dtype=torch.uint8, device=gpu)
+        g = torch.empty_like(rif)
+        st = torch.zeros(3, dtype=torch.int64, device=gpu)
+        lib.drrt_set_order_hint(p(order), n)
+        if hint:
+            lib.drrt_set_step_hint(p(fsteps), n)
+        _lib.check(lib.drrt_backtrace_f32(p(rif), rif.numel(), res, n, p(xt_d), p(vt_d), p(dx_d), p(dv_d), h, ds, p(g), p(st),
+                                          p(ws), ws.numel(), flags, None))
+        torch.cuda.synchronize()
+        assert int(st[0]) == ob["steps_total"], name
+        grads[name] = g.cpu().numpy()
+        assert cases.rel_l2(grads[name], ob["grad"]) <= 2e-5, name
+    for name in ("ring+steps", "ring", "box"):
+        assert cases.rel_l2(grads[name], grads["direct"]) <= 2e-5, name
+
+
 def test_q16_ray_state_mode(gpu, drrt_mod):
     """16-bit ray state "q16" (include/drrt_hip.h): trace_q16io / backtrace_q16io widen exactly, march in fp32 and round
     once -- trace_q16io(enc(x), enc(v)) == enc(trace_f32(dec(enc(x)), dec(enc(v)))) bit for bit, and the adjoint from
@@ -767,7 +853,7 @@ def test_q16_ray_state_mode(gpu, drrt_mod):
     assert bq.tolist()[0] == [32767, -32768, -32768]
     xt_q, vt_q = T.trace(rif, rif.shape, xq, vq, h, ds)
     st_q = drrt_mod.read_stats()
-    order = drrt_mod.last_order
+    order = drrt_mod.keep_order(drrt_mod.last_order)
     xt_f, vt_f = T.trace(rif, rif.shape, x0, v0, h, ds)
     assert drrt_mod.read_stats() == st_q
     ex, ev = drrt_mod.encode_rays16(rif.shape, h, xt_f, vt_f)

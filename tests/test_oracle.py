@@ -90,6 +90,20 @@ def test_cyl_eval_grad_matches_reference_cable(oracle):
     assert np.all(g[0] == 0.0)                      # r = 0 branch (:56)
 
 
+def test_fiber_demo_radial_lookup_matches_reference_cable():
+    """examples/fiber_demo.py does the boundary-index lookup of the fibre experiment (core/fiber_opt.py:158-160:
+    `Cable.GetLinear`, core/cable.py:92-119) with three lines of torch instead of a Cable mirror: pinned here, VALUES
+    only, by the fixture the reference's own Cable.GetLinear produced (getlinear_cable.npz 'f'), clamped tail included."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import fiber_demo
+    z = load("getlinear_cable.npz")
+    f = fiber_demo.radial_index(torch.from_numpy(z["prof"]), float(z["radius"]), torch.from_numpy(z["pts"]))
+    assert np.abs(f.numpy() - z["f"]).max() < 1e-13
+
+
 @pytest.mark.parametrize("tag", ["h1", "h05"])
 def test_adjoint_is_exact_discrete_adjoint(oracle, tag):
     """torch.autograd (float64) through the torch restatement of trace vs Tracer::backtrace.
