@@ -48,10 +48,10 @@ B_ADJ = 64.0                   # adjoint: 8 taps read + 8 fp32 atomic adds
 # Committed rocprofv3 PMC summary (tools/profile_bench.sh + tools/condense_profile.py on THIS command) that
 # `roofline.traffic` and the physical-bound figures are read from.  It is NOT measured in the run: the
 # bench line says so in `traffic_source` / `pmc_source`.
-PMC_PROFILE = os.path.join("profiles", "r3_pmc.json")
-PMC_FALLBACK = os.path.join("profiles", "r2_pmc.json")
+PMC_PROFILE = os.path.join("profiles", "r4_pmc.json")
+PMC_FALLBACK = os.path.join("profiles", "r3_pmc.json")
 N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMDs
-CLK_HZ = 2.4e9                 # nominal shader clock (the chip may hold less under load; stated, not measured)
+CLK_HZ = 2.4e9                 # nominal shader clock: only used when the PMC summary has no measured effective clock
 VALU_CYCLES = 4.0              # a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU counts
                                # exactly one quad-cycle per instruction on these kernels; tools/valu_bench.hip: 3.9)
 TA_CYCLES_PER_GATHER = 30.0    # a divergent 64-lane gather instruction occupies its CU's texture addresser for ~30-37 cycles,
@@ -289,18 +289,37 @@ def pmc_kernel(pmc, *prefixes):
 
 
 def physical_bound(pk, ms):
-    """Which on-chip unit bounds a march kernel, from the PMC summary `pk` of the same command and the live kernel
-    time `ms`: VALU issue (instructions x 4 cycles per SIMD) vs the texture addresser (gather INSTRUCTIONS x ~30 cycles
-    per CU -- its cost does not depend on how many lanes are active)."""
+    """What physically limits a march kernel, from the PMC summary `pk` of the same command and the live kernel time `ms`.
+    The clock is the MEASURED effective clock of the profiled dispatch (GRBM_GUI_ACTIVE / 8 / duration, tools/
+    condense_profile.py) when the summary has it; the nominal 2.4 GHz otherwise, and the line says which.
+      valu_issue_frac   VALU instructions x 4 cycles / (SIMDs x kernel cycles): the share of the kernel the vector pipes need
+                        if nothing else stood in the way (an upper bound on how much faster FEWER instructions could make it)
+      valu_busy_frac    the same from SQ_ACTIVE_INST_VALU (quad-cycles the pipes were actually busy)
+      wait_frac         SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: share of resident wave-cycles spent waiting (dependent chain:
+                        gather and LDS round trips, branches)
+      ta_gather_frac_est  gather INSTRUCTIONS x ~30 cycles per CU (the texture addresser's cost does not depend on how
+                        many lanes are active)
+    DESIGN.md 5: the adjoint responds to added VALU work at about a quarter of its issue time, i.e. it is bound by the
+    wave's dependent chain per step WITH the vector pipes ~80 % busy -- hence the name of the bound."""
     out = {}
     if ms != ms or ms <= 0 or not pk:
         return out
-    cyc = ms * 1e-3 * CLK_HZ
+    clk_ghz = pk.get("effective_clock_ghz")
+    out["clock_ghz"] = clk_ghz if clk_ghz else CLK_HZ / 1e9
+    out["clock_source"] = ("measured: GRBM_GUI_ACTIVE / 8 / dispatch duration of the profiled run (committed PMC summary)"
+                           if clk_ghz else "ASSUMED nominal clock (the PMC summary carries no GRBM_GUI_ACTIVE pass)")
+    cyc = ms * 1e-3 * out["clock_ghz"] * 1e9
     valu = ta = None
     if "SQ_INSTS_VALU" in pk:
         valu = pk["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMD * cyc)
         out["valu_issue_frac"] = valu
         out["valu_insts_per_launch_pmc"] = pk["SQ_INSTS_VALU"]
+    if "SQ_ACTIVE_INST_VALU" in pk:
+        out["valu_busy_frac"] = pk["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cyc)
+    if "wait_frac" in pk:
+        out["wait_frac"] = pk["wait_frac"]
+    elif "SQ_WAIT_INST_ANY" in pk and pk.get("SQ_WAVE_CYCLES"):
+        out["wait_frac"] = pk["SQ_WAIT_INST_ANY"] / pk["SQ_WAVE_CYCLES"]
     if "SQ_INSTS_VMEM_RD" in pk:
         ta = pk["SQ_INSTS_VMEM_RD"] * TA_CYCLES_PER_GATHER / (N_CU * cyc)
         out["ta_gather_frac_est"] = ta
@@ -308,14 +327,15 @@ def physical_bound(pk, ms):
     if valu is None and ta is None:
         return out
     if ta is None or (valu is not None and valu >= ta):
-        out["physical_bound"], out["physical_frac"] = "valu_issue", valu
+        out["physical_bound"], out["physical_frac"] = "dependent_chain+valu_issue", valu
     else:
         out["physical_bound"], out["physical_frac"] = "texture_addresser_gather_instructions", ta
     out["physical_note"] = (f"taps are served by L1/L2/Infinity Cache (the 64 MiB grid is cache-resident), so HBM is not the "
-                            f"physical limiter; fractions assume the nominal {CLK_HZ / 1e9:.1f} GHz clock, VALU = "
-                            f"{VALU_CYCLES:.0f} cycles per wave64 instruction per SIMD (tools/valu_bench.hip: 3.9-4.8), a "
-                            f"gather instruction = {TA_CYCLES_PER_GATHER:.0f} cycles of its CU's texture addresser "
-                            f"(tools/chain_bench.hip: 30-37); instruction counts from the committed PMC summary")
+                            f"physical limiter; VALU = {VALU_CYCLES:.0f} cycles per wave64 instruction per SIMD "
+                            f"(tools/valu_bench.hip: 3.9-4.8), a gather instruction = {TA_CYCLES_PER_GATHER:.0f} cycles of its "
+                            f"CU's texture addresser (tools/chain_bench.hip: 30-37); instruction counts and clock from the "
+                            f"committed PMC summary; physical_frac = the VALU issue share, the rest of the kernel time is the "
+                            f"wave's dependent chain (wait_frac) that the resident waves do not hide")
     return out
 
 
@@ -645,7 +665,7 @@ def run_rank(args) -> int:
         ach_adj = adj_steps * B_ADJ / (ms_adj * 1e-3) / 1e9
         ach_fwd = fwd_steps * B_FWD / (ms_fwd * 1e-3) / 1e9
         default_cfg = (R == 256 and n == 1024 * 1024 and world == 1 and not args.no_sort and not args.direct_atomics
-                       and not args.experiment and args.pair == "auto" and not args.fwd_flags
+                       and not args.experiment and args.pair == "auto" and not args.fwd_flags and not args.shard_of
                        and not args.adj_flags and args.workload == "metric" and args.source_axis == "y")
         pmc, pmc_src = load_pmc() if default_cfg else (None, None)
         pk_adj = pmc_kernel(pmc, "drrt::k_backtrace_flat", "drrt::k_backtrace_win")
@@ -712,6 +732,11 @@ def run_rank(args) -> int:
                          # adjoint of half B doubles the bytes on the wire and cannot shorten the step)
                          "allreduce_exposed": m["ms_allreduce"] if use_dist else None},
             "fwd_only_ray_steps_per_s_per_gpu": fwd_steps / (ms_fwd * 1e-3),
+            # the whole step's algorithmic bytes (32 B per forward + 64 B per adjoint ray-step) per second over
+            # the HBM peak: above 1 means SURVEY's byte model is exhausted as a yardstick (the taps are cache-served) --
+            # the bound that physically applies is in roofline.physical_bound / valu_issue_frac / wait_frac
+            "whole_step_algorithmic_over_peak": (fwd_steps * B_FWD + adj_steps * B_ADJ) / (m["elapsed"] / args.steps)
+                                                / 1e9 / HBM_PEAK_GBS,
         }
         if "weak" in results and main_mode != "weak":
             w = results["weak"]

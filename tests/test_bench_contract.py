@@ -47,8 +47,25 @@ def test_bench_line_contract(gpu):
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert d["parity_check"]["ok"] is True
     v = d["variants"]
-    for name in ("cube6_rotated", "plane_shifted"):
+    for name in ("cube6_rotated", "plane_shifted", "tomo_weak"):
         assert v[name]["grad_rel_l2_vs_direct_atomics"] <= 2e-5 and v[name]["n_failed"] == 0
         assert v[name]["adj_ns_ratio_to_headline"] > 0
+        assert v[name]["adjoint_kernel"]["kernel"] in ("box", "ring")
+    # which adjoint kernel the device-side classification chose (a drifting threshold / sort key would show here)
+    assert d["config"]["adjoint_kernel"]["kernel"] == "box" and v["cube6_rotated"]["adjoint_kernel"]["kernel"] == "ring"
+    # the line states itself that SURVEY's byte model is exceeded and which bound physically applies
+    assert d["whole_step_algorithmic_over_peak"] > 0
+    for k in ("physical_bound", "physical_frac", "valu_issue_frac", "clock_ghz", "clock_source"):
+        assert k in ro, k
     ph = d["phase_ms"]
     assert ph["sort_avg"] + (ph["pair_copy"] or 0.0) + ph["trace"] + ph["backtrace"] <= d["ms_per_step"] * 1.02
+
+
+def test_bench_refuses_to_report_a_value_when_parity_fails(gpu):
+    """A throughput whose kernels disagree with the oracle is not a result: with the adjoint ablated (development
+    switch: no gradient emission) the run must print no `value` and exit non-zero."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "2",
+                        "--no-variants", "--experiment", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d["value"] is None and d["parity_check"]["ok"] is False and "error" in d

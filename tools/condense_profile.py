@@ -38,6 +38,7 @@ if stats:
 pmc = collections.defaultdict(dict)
 for f in [g for d in sorted(glob.glob(f"{src}/pmc_*")) for g in newest(f"{d}/runc/*_counter_collection.csv")]:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    clk = collections.defaultdict(list)               # kernel -> [(GRBM_GUI_ACTIVE, dispatch duration in ns)]
     for r in csv.DictReader(open(f)):
         if "drrt::" not in r["Kernel_Name"]:
             continue
@@ -45,9 +46,21 @@ for f in [g for d in sorted(glob.glob(f"{src}/pmc_*")) for g in newest(f"{d}/run
         agg[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[kn]["_VGPR"] = [float(r["VGPR_Count"])]
         agg[kn]["_LDS_bytes_per_block"] = [float(r["LDS_Block_Size"])]
+        dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        agg[kn]["_dispatch_ns_under_pmc"].append(dur)
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            clk[kn].append((float(r["Counter_Value"]), dur))
     for kn, c in agg.items():
         for k, v in c.items():
             pmc[kn][k] = sum(v) / len(v)
+    for kn, v in clk.items():
+        # effective shader clock = GRBM_GUI_ACTIVE (sum over the 8 XCDs) / 8 / dispatch duration; dispatches that return at
+        # once (the adjoint kernel the bundle classification did not pick) read high and are left out
+        dmax = max(d for _, d in v)
+        live = [(c_, d) for c_, d in v if d >= 0.5 * dmax and d > 0]
+        if live:
+            pmc[kn]["effective_clock_ghz"] = sum(c_ / 8.0 / d for c_, d in live) / len(live)
+            pmc[kn]["effective_clock_dispatch_ns"] = sum(d for _, d in live) / len(live)
 for kn, c in list(pmc.items()):
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE
@@ -57,6 +70,8 @@ for kn, c in list(pmc.items()):
         c["hbm_read_bytes_x2"] = c["FETCH_SIZE"] * 2048
         c["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
         c["hbm_traffic_bytes_per_launch"] = c["hbm_read_bytes_x2"] + c["hbm_write_bytes"]
+    if "SQ_WAIT_INST_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+        c["wait_frac"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]        # share of wave-cycles spent waiting on anything
 meta = {"tag": tag}
 for b in glob.glob(f"{src}/bench_trace.json"):
     open(f"profiles/{tag}_bench_under_rocprof.json", "w").write(open(b).read())

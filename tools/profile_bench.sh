@@ -14,5 +14,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- $B > $out/bench_write.json 2> $out/write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $out/pmc_sq -- $B > $out/bench_sq.json 2> $out/sq.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $out/pmc_tcc -- $B > $out/bench_tcc.json 2> $out/tcc.err
+# effective shader clock of every dispatch: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / dispatch duration (MI355X_MICROARCH.md, DVFS)
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_clk -- $B > $out/bench_clk.json 2> $out/clk.err
 find $out -name "*.csv" | head -30
 for f in $out/*.err; do tail -n 2 "$f" | cut -c1-200; done
