@@ -65,6 +65,9 @@ SIGNATURES = {
     "drrt_trace_sdf_f32": (_i, [_vp, _vp, _ll, _vp, _sz, _vp, _vp, _f, _f, _vp, _vp] + _tail),
     "drrt_trace_cable_f32": (_i, [_vp, _sz, _f, _f, _sz, _vp, _vp, _vp, _f, _vp, _vp, _vp] + _tail),
     "drrt_backtrace_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
+    "drrt_backtrace_chunk_state_bytes": (_sz, [_sz]),
+    "drrt_backtrace_max_steps": (_i, [_vp, _f, _f]),
+    "drrt_backtrace_chunk_f32": (_i, [_vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail + [_vp, _sz, _i, _i, _vp]),
     "drrt_backtrace_sdf_f32": (_i, [_vp, _vp, _ll, _vp, _sz, _vp, _vp, _vp, _vp, _f, _f, _vp] + _tail),
     "drrt_backtrace_cable_f32": (_i, [_vp, _sz, _f, _f, _sz, _vp, _vp, _vp, _vp, _f, _vp] + _tail),
     "drrt_sensor_splat_f32": (_i, [_sz, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _f, _vp, _u, _vp]),

@@ -229,7 +229,13 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
 // ring kernel in round 3 and are gone.)
 // MODE: 0 = backtrace, 1 = backtrace_sdf (the ray also ends where the sdf sample turns non-negative, :488-497; the sdf
 //       taps ride along with the grid's taps).
-template <bool ABL, bool PAIR, int MODE = 0>
+// CHUNK: the resumable instantiation behind drrt_backtrace_chunk_f32 (depth-chunked adjoint for the multi-GPU slab reduce,
+//       DESIGN.md section 7): the launch marches a.max_steps iterations of every ray, starting from the exit rays or from
+//       the state the previous chunk left in a.chunk_state (12 floats + a flag word per visit slot, SoA), hands every
+//       accumulator over and flushes every window at its end, saves the state, and reduces the bounding box of the positions
+//       and velocities of the rays that are still marching into a.chunk_progress.  Same arithmetic, same contributions;
+//       only the order in which they reach the grid differs from the one-launch march.
+template <bool ABL, bool PAIR, int MODE = 0, bool CHUNK = false>
 __global__ void __launch_bounds__(kAdjBlock, DRRT_ADJ_WAVES) k_backtrace_flat(BackArgs a) {
   if (a.select != nullptr && bundles_want_ring(a.select)) return;
   constexpr int kSlots = kWinFloats;
@@ -245,7 +251,15 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_ADJ_WAVES) k_backtrace_flat(Ba
   s.x = s.y = s.z = s.vx = s.vy = s.vz = s.lx = s.ly = s.lz = s.mx = s.my = s.mz = 0.f;
   s.active = false; s.outside = false;
   size_t i;
-  if (ray_index(a.perm, t, a.n, i)) {
+  const bool resume = CHUNK && a.chunk_resume != 0;
+  if (resume) {                                                // continue where the previous chunk stopped
+    const size_t S = a.chunk_stride;
+    const float* cs = a.chunk_state + t;
+    const unsigned fl = __float_as_uint(cs[12 * S]);
+    s.x = cs[0]; s.y = cs[S]; s.z = cs[2 * S]; s.vx = cs[3 * S]; s.vy = cs[4 * S]; s.vz = cs[5 * S];
+    s.lx = cs[6 * S]; s.ly = cs[7 * S]; s.lz = cs[8 * S]; s.mx = cs[9 * S]; s.my = cs[10 * S]; s.mz = cs[11 * S];
+    s.active = (fl & 1u) != 0u; s.outside = (fl & 2u) != 0u;
+  } else if (ray_index(a.perm, t, a.n, i)) {
     Ray3 p = ld3(a.xt, i, a.io_half, &a.vol, RAY_POS), u = ld3(a.vt, i, a.io_half, &a.vol, RAY_VEL), gxv = ld3(a.dx, i, a.io_half), gvv = ld3(a.dv, i, a.io_half);
     s.x = p.x; s.y = p.y; s.z = p.z; s.vx = u.x; s.vy = u.y; s.vz = u.z;
     adj_init(V, a.ds, gxv.x, gxv.y, gxv.z, gvv.x, gvv.y, gvv.z, s);
@@ -272,8 +286,8 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_ADJ_WAVES) k_backtrace_flat(Ba
   bool miss = false;                                         // the cell just entered lies outside the window
   const TapRows R = tap_rows<PAIR>(V);                       // wave-uniform row pointers + ONE 32-bit byte offset per lane
   // step to the next sample (:420), locate its cell in place and issue its gather unless the lane holds those taps
-  auto step_locate = [&](int& nbase, bool& nregular) {
-    s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z);
+  auto step_locate = [&](int& nbase, bool& nregular, bool move = true) {      // move = false: locate only (a resumed ray)
+    if (move) { s.x = fmaf(-a.ds, s.vx, s.x); s.y = fmaf(-a.ds, s.vy, s.y); s.z = fmaf(-a.ds, s.vz, s.z); }
     const float fx = s.x * V.inv_h, fy = s.y * V.inv_h, fz = s.z * V.inv_h;
     ix = cvt_floor_i32(fx); iy = cvt_floor_i32(fy); iz = cvt_floor_i32(fz);
     interior = (((unsigned)ix - 1u) < V.lx) & (((unsigned)iy - 1u) < V.ly) & (((unsigned)iz - 1u) < V.lz);
@@ -300,7 +314,8 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_ADJ_WAVES) k_backtrace_flat(Ba
   };
   if (s.active) {
     int nbase; bool nregular;
-    step_locate(nbase, nregular);                            // first sample
+    if (resume) step_locate(nbase, nregular, false);         // the saved position IS the next sample
+    else        step_locate(nbase, nregular);                // first sample
     base = nbase; regular = nregular;
     miss = regular;                                          // no window yet
   }
@@ -308,6 +323,8 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_ADJ_WAVES) k_backtrace_flat(Ba
   int cooldown = 0;
   unsigned steps = 0;
   unsigned n_flush = 0;
+  // CHUNK: bounding box of the samples this launch contributes at (which voxels it can have touched)
+  float bx0 = 3.0e38f, by0 = 3.0e38f, bz0 = 3.0e38f, bx1 = -3.0e38f, by1 = -3.0e38f, bz1 = -3.0e38f;
   // event counters of the debug instantiation (a.dbg): [4] one-face leaves handed to the window, [5] of those, lanes that
   // issued the LDS adds after the pair / quad pre-reduction, [6] one-face leaves that went to global atomics (cell outside
   // the window), [7] leaves that handed over all eight corners, [8] wave-steps, [9] wave-steps with leaves across >= 2 axes
@@ -379,6 +396,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_ADJ_WAVES) k_backtrace_flat(Ba
           if (regular && experiment != 1) used_lds = flat_emit8<true>(win, WSY, WSZ, a.grad, V.sy, V.sz, lidx, base, p00, p10, p01, p11);
         } else {
           ++steps;
+          if (CHUNK) { bx0 = fminf(bx0, px); by0 = fminf(by0, py); bz0 = fminf(bz0, pz); bx1 = fmaxf(bx1, px); by1 = fmaxf(by1, py); bz1 = fmaxf(bz1, pz); }
           {
             // first half of adj_contrib: the 8 splat weights (they need the in-cell fractions of THIS cell)
             const float dn = dot3(s.mx, s.my, s.mz, m.gx, m.gy, m.gz);                            // :430
@@ -512,6 +530,35 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_ADJ_WAVES) k_backtrace_flat(Ba
     win_flush(win, W.ox, W.oy, W.oz, a.grad, V, lane, experiment == 2);
     ++n_flush;
   }
+  if (CHUNK) {
+    // the state the next chunk resumes from (position = the next sample, already stepped to), and where the rays that are
+    // still marching stand and head: bounding boxes of their positions [0..5] and velocities [6..11] as order-preserving
+    // integer keys (min: 0..2 / 6..8, max: 3..5 / 9..11), [12] their number; [13..18] bounding box of the samples taken
+    const size_t S = a.chunk_stride;
+    float* cs = a.chunk_state + t;
+    cs[0] = s.x; cs[S] = s.y; cs[2 * S] = s.z; cs[3 * S] = s.vx; cs[4 * S] = s.vy; cs[5 * S] = s.vz;
+    cs[6 * S] = s.lx; cs[7 * S] = s.ly; cs[8 * S] = s.lz; cs[9 * S] = s.mx; cs[10 * S] = s.my; cs[11 * S] = s.mz;
+    cs[12 * S] = __uint_as_float((s.active ? 1u : 0u) | (s.outside ? 2u : 0u));
+    if (a.chunk_progress != nullptr && __any(s.active)) {
+      const float vals[6] = {s.x, s.y, s.z, s.vx, s.vy, s.vz};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int key = float_order_key(vals[k]);
+        const int lo = wave_min_i32(s.active ? key : 0x7fffffff), hi = wave_max_i32(s.active ? key : (int)0x80000000);
+        if (lane == 0) { atomicMin(&a.chunk_progress[(k / 3) * 6 + (k % 3)], lo); atomicMax(&a.chunk_progress[(k / 3) * 6 + 3 + (k % 3)], hi); }
+      }
+      const unsigned cnt = (unsigned)__popcll(__ballot(s.active));
+      if (lane == 0) atomicAdd((unsigned*)&a.chunk_progress[12], cnt);
+    }
+    if (a.chunk_progress != nullptr && __any(steps != 0u)) {       // [13..15] min, [16..18] max of the samples of THIS chunk
+      const float lo[3] = {bx0, by0, bz0}, hi[3] = {bx1, by1, bz1};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int l = wave_min_i32(float_order_key(lo[k])), h = wave_max_i32(float_order_key(hi[k]));
+        if (lane == 0) { atomicMin(&a.chunk_progress[13 + k], l); atomicMax(&a.chunk_progress[16 + k], h); }
+      }
+    }
+  }
   if (ABL && a.dbg) {
     if (lane == 0) atomicAdd(&a.dbg[0], (unsigned long long)n_flush);
     if (ev_face) atomicAdd(&a.dbg[4], (unsigned long long)ev_face);
@@ -536,6 +583,11 @@ void launch_bundle_classify(const BackArgs& a, hipStream_t s) {
 void launch_backtrace_box(int mode, bool abl, const BackArgs& a, hipStream_t s) {
   const dim3 g(adj_grid_for(a.n)), b(kAdjBlock);
   const bool pair = a.vol.pair != nullptr;
+  if (a.chunk_state != nullptr) {      /* resumable march (drrt_backtrace_chunk_f32): backtrace only */
+    if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true, 0, true>), g, b, 0, s, a);
+    else      hipLaunchKernelGGL((k_backtrace_flat<false, false, 0, true>), g, b, 0, s, a);
+    return;
+  }
   if (mode == 1) {          /* the ablation / counter instantiation exists for backtrace only */
     if (pair) hipLaunchKernelGGL((k_backtrace_flat<false, true, 1>), g, b, 0, s, a);
     else      hipLaunchKernelGGL((k_backtrace_flat<false, false, 1>), g, b, 0, s, a);

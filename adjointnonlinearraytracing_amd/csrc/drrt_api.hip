@@ -415,11 +415,21 @@ extern "C" int drrt_trace_target_f32(const float* rif, long long nvox, const int
   return DRRT_OK;
 }
 
+// One chunk of a resumable adjoint march (drrt_backtrace_chunk_f32)
+struct ChunkReq { void* state; size_t state_bytes; int it_begin, it_count; int* progress; };
+
+namespace drrt {
+__global__ void k_chunk_progress_init(int* p) {
+  const int k = threadIdx.x;              // [0..11] mins, maxs, mins, maxs; [12] count; [13..18] mins, maxs; [19] spare
+  if (k < 20) p[k] = (k == 12 || k == 19) ? 0 : ((((k < 12 ? k : k - 1) / 3) & 1) ? (int)0x80000000 : 0x7fffffff);
+}
+}  // namespace drrt
+
 template <int MODE>
 static int run_backtrace(const float* rif, const float* sdf, long long nvox, const int res[3], size_t n,
                          const void* xt, const void* vt, const void* dx, const void* dv,
                          float h, float ds, float* grad, drrt_stats* stats, void* ws, size_t ws_bytes,
-                         unsigned flags, void* stream, int io_half = 0) {
+                         unsigned flags, void* stream, int io_half = 0, const ChunkReq* ck = nullptr) {
   const OrderHint hint = take_hint();
   g_last_counters = nullptr;              // set again below when this call classifies its bundles
   g_err[0] = 0;
@@ -429,12 +439,21 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   rc = check_steps(h, ds); if (rc) return rc;
   if (!grad) return fail(DRRT_ERR_ARG, "null grad pointer");
   if (MODE == 1 && !sdf) return fail(DRRT_ERR_ARG, "null sdf pointer");
-  if (!(flags & DRRT_FLAG_NO_ZERO)) {                                        // src/tracer.cpp:401-403
+  const bool first_chunk = ck == nullptr || ck->it_begin == 0;
+  if (ck != nullptr) {
+    if (ck->it_begin < 0) return fail(DRRT_ERR_ARG, "chunk: it_begin must be >= 0");
+    if (flags & DRRT_FLAG_DIRECT_ATOMICS) return fail(DRRT_ERR_ARG, "chunk: not available with DRRT_FLAG_DIRECT_ATOMICS");
+    if (!ck->state || ck->state_bytes < drrt_backtrace_chunk_state_bytes(n))
+      return fail(DRRT_ERR_ARG, "chunk: state buffer too small (see drrt_backtrace_chunk_state_bytes)");
+    if (!first_chunk && (flags & DRRT_FLAG_SORT_RAYS) && !(hint.order && hint.n == n))
+      return fail(DRRT_ERR_ARG, "chunk: a resumed chunk needs the visit order of its first chunk (drrt_set_order_hint)");
+  }
+  if (!(flags & DRRT_FLAG_NO_ZERO) && first_chunk) {                         // src/tracer.cpp:401-403
     ProfScope prof(DRRT_PROF_ZERO, s);
     hipError_t e = hipMemsetAsync(grad, 0, (size_t)nvox * sizeof(float), s);
     if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(grad)");
   }
-  rc = zero_stats(stats, s); if (rc) return rc;
+  if (first_chunk) { rc = zero_stats(stats, s); if (rc) return rc; }
   if (n == 0) return DRRT_OK;
   if (!xt || !vt || !dx || !dv) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
@@ -443,6 +462,14 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   a.io_half = io_half;
   a.sdf = sdf; a.xt = xt; a.vt = vt; a.dx = dx; a.dv = dv; a.grad = grad; a.stats = stats;
   a.n = n; a.ds = ds; a.max_steps = steps_adj(h, res, ds);
+  if (ck != nullptr) {                      // the iterations [it_begin, it_begin + it_count) of the march's max_steps
+    const int left = a.max_steps - ck->it_begin;
+    a.max_steps = ck->it_count < 0 ? left : (ck->it_count < left ? ck->it_count : left);
+    if (a.max_steps < 0) a.max_steps = 0;
+    a.chunk_state = (float*)ck->state; a.chunk_stride = (size_t)adj_grid_for(n) * kAdjBlock;
+    a.chunk_resume = first_chunk ? 0 : 1; a.chunk_progress = ck->progress;
+    if (ck->progress) { hipLaunchKernelGGL(drrt::k_chunk_progress_init, dim3(1), dim3(64), 0, s, ck->progress); LAUNCH_CHECK("k_chunk_progress_init"); }
+  }
   a.grad_scale = (flags & DRRT_FLAG_CORRECTED_H) ? a.vol.inv_h : 1.0f;
   a.experiment = (int)((flags >> 8) & 0xffu);
   a.fsteps = (hint.steps && hint.steps_n == n) ? hint.steps : nullptr;
@@ -467,7 +494,8 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
       // DRRT_FLAG_STATIC_WINDOW / DRRT_FLAG_RING_WINDOW force one of the two (A-B).
       a.select = nullptr;
       const size_t ctr_off = (drrt_workspace_bytes(n, flags) + ((flags & DRRT_FLAG_PAIR_GRID) ? (size_t)nvox * 2 * sizeof(float) : 0) + 7) & ~(size_t)7;
-      const bool force_box = (flags & DRRT_FLAG_STATIC_WINDOW) != 0 || a.experiment == 7, force_ring = (flags & DRRT_FLAG_RING_WINDOW) != 0;
+      const bool force_box = (flags & DRRT_FLAG_STATIC_WINDOW) != 0 || a.experiment == 7 || ck != nullptr;   // chunks: box-window kernel only
+      const bool force_ring = (flags & DRRT_FLAG_RING_WINDOW) != 0 && ck == nullptr;
       if (!force_box && !force_ring && a.perm != nullptr && ws && ws_bytes >= ctr_off + 512) {
         a.select = (unsigned*)((char*)ws + ctr_off + 256);
         g_last_counters = a.select;
@@ -488,6 +516,20 @@ extern "C" int drrt_backtrace_f32(const float* rif, long long nvox, const int re
                                   float h, float ds, float* grad, drrt_stats* stats, void* ws,
                                   size_t ws_bytes, unsigned flags, void* stream) {
   return run_backtrace<0>(rif, nullptr, nvox, res, n, xt, vt, dx, dv, h, ds, grad, stats, ws, ws_bytes, flags, stream);
+}
+
+extern "C" size_t drrt_backtrace_chunk_state_bytes(size_t n) { return (size_t)adj_grid_for(n) * kAdjBlock * 13 * sizeof(float); }
+extern "C" int drrt_backtrace_max_steps(const int res[3], float h, float ds) {
+  if (!res || !(h > 0.f) || !(ds > 0.f)) return -1;
+  return steps_adj(h, res, ds);
+}
+extern "C" int drrt_backtrace_chunk_f32(const float* rif, long long nvox, const int res[3], size_t n,
+                                        const float* xt, const float* vt, const float* dx, const float* dv,
+                                        float h, float ds, float* grad, drrt_stats* stats, void* ws,
+                                        size_t ws_bytes, unsigned flags, void* stream, void* state, size_t state_bytes,
+                                        int it_begin, int it_count, int* progress) {
+  const ChunkReq ck{state, state_bytes, it_begin, it_count, progress};
+  return run_backtrace<0>(rif, nullptr, nvox, res, n, xt, vt, dx, dv, h, ds, grad, stats, ws, ws_bytes, flags, stream, 0, &ck);
 }
 
 extern "C" int drrt_backtrace_f16io(const float* rif, long long nvox, const int res[3], size_t n,

@@ -263,7 +263,25 @@ struct BackArgs {
   unsigned* select;            // nullable (k_backtrace_flat): [0] waves a fitted window would help, [1] waves classified
   const uint32_t* fsteps;      // nullable: per-ray iteration counts of the forward march that produced (xt, vt) (step hint)
   int xcd_order;               // 1: the launch's blocks take the visit order XCD by XCD (xcd_block)
+  // resumable march (drrt_backtrace_chunk_f32; k_backtrace_flat<..., CHUNK = true>): nullable
+  float* chunk_state;          // 13 words per visit slot, SoA with stride chunk_stride: x, v, lambda, mu, flags
+  size_t chunk_stride;         // visit slots of the launch (grid * block)
+  int chunk_resume;            // 0: start from (xt, vt, dx, dv); 1: continue from chunk_state
+  int* chunk_progress;         // nullable: 13 ints, see drrt_backtrace_chunk_f32
 };
+
+// order-preserving integer key of a float (for atomicMin / atomicMax on floats of either sign); its own inverse
+__host__ __device__ inline int float_order_key(float f) {
+  int i;
+  memcpy(&i, &f, sizeof(i));
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ inline float float_from_order_key(int k) {
+  const int i = k >= 0 ? k : k ^ 0x7fffffff;
+  float f;
+  memcpy(&f, &i, sizeof(f));
+  return f;
+}
 
 // Accumulators are DOUBLES: measured on gfx950 (tools/lds_atomic_bench.hip) ds_add_f32 costs ~193
 // cycles per wave-instruction per CU even without address collisions (~3 cycles per lane), while

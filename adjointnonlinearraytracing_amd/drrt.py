@@ -340,6 +340,22 @@ def read_bundle_counters() -> Optional[Dict[str, int]]:
                 ring_threshold_pct=pct, kernel="ring" if (c[0] and c[0] * 100 >= c[1] * pct) else "box")
 
 
+def decode_chunk_progress(progress: torch.Tensor) -> Dict[str, object]:
+    """Synchronising read of a chunk's progress block (drrt_backtrace_chunk_f32) -> dict(active, pos_min, pos_max, vel_min,
+    vel_max, sample_min, sample_max): the bounding boxes of where the still-marching rays stand and head, and of the
+    samples the chunk contributed at (lists of 3 floats; None when there is no such ray / sample)."""
+    k = progress.cpu().to(torch.int64)
+    n_active = int(k[12]) & 0xFFFFFFFF
+    bits = torch.where(k >= 0, k, k ^ 0x7FFFFFFF).to(torch.int32)
+    f = bits.view(torch.float32).tolist()
+    out = dict(active=n_active, pos_min=None, pos_max=None, vel_min=None, vel_max=None, sample_min=None, sample_max=None)
+    if n_active:
+        out.update(pos_min=f[0:3], pos_max=f[3:6], vel_min=f[6:9], vel_max=f[9:12])
+    if int(k[13]) != 0x7FFFFFFF:
+        out.update(sample_min=f[13:16], sample_max=f[16:19])
+    return out
+
+
 def _hint(order: Optional[torch.Tensor], n: int) -> bool:
     """Arm the library's order (and step) hint for the next march call; -> whether an order was handed over."""
     if order is not None and order.numel() == n and order.dtype == torch.int32 and order.is_cuda:
@@ -553,6 +569,53 @@ class TracerC:
                     _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
                     float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
                 _capture_counters(ws)
+            finally:
+                _clear_hint()
+        return grad
+
+    def backtrace_chunked(self, rif, res, xt, vt, dx, dv, h, ds, order: Optional[torch.Tensor] = None, chunks: int = 4,
+                          on_chunk=None) -> torch.Tensor:
+        """Tracer::backtrace in `chunks` depth chunks (drrt_backtrace_chunk_f32, include/drrt_hip.h): the same gradient as
+        ``backtrace`` (same per-ray contributions, another summation order), computed by `chunks` launches of
+        max_steps / chunks iterations each.  After every chunk ``on_chunk(k, grad, progress)`` is called with the running
+        gradient (flat fp32[nvox], still being accumulated into by the later chunks) and ``progress`` = a device tensor of
+        20 int32 (decode with ``decode_chunk_progress``): the bounding box of the positions and velocities of the rays
+        that are still marching -- what lies behind all of them, with none heading back, is final -- and the box of the
+        samples this chunk contributed at.  Not in the reference;
+        used by ``dist`` to reduce final slabs of dL/dn across ranks while the next chunk marches.  fp32 rays only."""
+        dev = _dev(rif)
+        with torch.cuda.device(dev):
+            order = _valid_order(order)
+            rif_, xt_ = _f32(rif, dev).reshape(-1), _rays(xt, dev)
+            n = xt_.shape[0]
+            vt_, dx_, dv_ = _rays(vt, dev, n), _rays(dx, dev, n), _rays(dv, dev, n)
+            grad = torch.empty_like(rif_)
+            fl = _flags(adjoint=True)
+            (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None, adjoint=True), _new_stats(dev)
+            lib = _lib.load()
+            total = int(lib.drrt_backtrace_max_steps(_res3(res), float(h), float(ds)))
+            if total < 0:
+                raise RuntimeError("h and ds must be positive and finite")
+            chunks = max(1, min(int(chunks), max(total, 1)))
+            state = torch.empty(int(lib.drrt_backtrace_chunk_state_bytes(n)), dtype=torch.uint8, device=dev)
+            bounds = [total * k // chunks for k in range(chunks + 1)]
+            try:
+                for k in range(chunks):
+                    progress = torch.empty(20, dtype=torch.int32, device=dev)
+                    if k == 0:
+                        if not _hint(order, n):
+                            _bump_order_gen(dev)           # the first chunk sorts for itself
+                    else:                                  # later chunks: the order the first chunk used
+                        if order is not None:
+                            _hint(order, n)
+                        elif fl & _lib.FLAG_SORT_RAYS:
+                            lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
+                    _lib.check(lib.drrt_backtrace_chunk_f32(
+                        _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_), float(h), float(ds),
+                        _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev), _p(state), state.numel(),
+                        bounds[k], bounds[k + 1] - bounds[k], _p(progress)))
+                    if on_chunk is not None:
+                        on_chunk(k, grad, progress)
             finally:
                 _clear_hint()
         return grad

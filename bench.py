@@ -90,6 +90,14 @@ def parse_args(argv=None):
                          "a G-GPU run does, without the all-reduce) -- per-shard timings for the scaling projection in "
                          "DESIGN.md (tools/run_shards.sh times every index and takes the max)")
     ap.add_argument("--shard-index", type=int, default=0, metavar="K", help="which shard of --shard-of (default 0)")
+    ap.add_argument("--adjoint-chunks", type=int, default=0, metavar="K",
+                    help="run the adjoint as K depth chunks (drrt_backtrace_chunk_f32: K launches of max_steps / K iterations, ray "
+                         "state carried through HBM, windows flushed at chunk ends) -- what the slab-wise all-reduce of "
+                         "dist.py needs; the line then carries `chunking` (the share of the grid that is final after each chunk)")
+    ap.add_argument("--overlap-reduce", action="store_true",
+                    help="N > 1 with --adjoint-chunks K: reduce the planes of dL/dn that are final after each chunk on a side "
+                         "stream while the next chunk marches (dist.SlabReducer) instead of one whole-grid all-reduce at the end; "
+                         "phase_ms.allreduce_exposed is then what is left after the last chunk")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the `variants` leg (the reference's six rotated views and the shifted plane source)")
@@ -493,7 +501,14 @@ def run_rank(args) -> int:
         dx, dv = torch.ones_like(pos), torch.ones_like(vel)          # adjoint seed dx=dv=1 (src/test.cpp:142-144)
         st_f = torch.zeros(3, dtype=torch.int64, device=dev)
         st_a = torch.zeros(3, dtype=torch.int64, device=dev)
+        K = max(0, args.adjoint_chunks)
+        if K > 1:
+            total_it = int(lib.drrt_backtrace_max_steps(res, h, ds))
+            cb = [total_it * k // K for k in range(K + 1)]
+            cstate = torch.empty(int(lib.drrt_backtrace_chunk_state_bytes(n)), dtype=torch.uint8, device=dev)
+            cprog = torch.zeros(K, 20, dtype=torch.int32, device=dev)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        overlap_info = {}
 
         def step(k=None):
             _lib.check(lib.drrt_trace_f32(p(rif), nvox, res, n, p(pos), p(vel), h, ds, p(xt), p(vt),
@@ -502,8 +517,35 @@ def run_rank(args) -> int:
                 lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
                 if not args.no_step_hint:                                    # ... on the forward march's clock
                     lib.drrt_set_step_hint(lib.drrt_last_steps(None), n)
-            _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),
-                                              p(st_a), p(ws), ws.numel(), aflags, stream))
+            overlap = K > 1 and use_dist and args.overlap_reduce
+            if K > 1:                                                        # the adjoint in K depth chunks
+                cev = []
+                for c in range(K):
+                    if c > 0 and (flags & _lib.FLAG_SORT_RAYS):              # every chunk visits the rays in the same order
+                        lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
+                    _lib.check(lib.drrt_backtrace_chunk_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),
+                                                            p(st_a), p(ws), ws.numel(), aflags, stream, p(cstate),
+                                                            cstate.numel(), cb[c], cb[c + 1] - cb[c], p(cprog[c])))
+                    if overlap:
+                        e_ = torch.cuda.Event(); e_.record(); cev.append(e_)
+                if overlap:                                                  # all chunks are queued: follow them as they finish
+                    from adjointnonlinearraytracing_amd import drrt as _drrt
+                    red = drrt_dist.SlabReducer(grad, (R, R, R), h)
+                    for c in range(K):
+                        cev[c].synchronize()
+                        red.after_chunk(_drrt.decode_chunk_progress(cprog[c]), cev[c])
+                    early = int(sum(int(b_.numel()) for _, b_, _ in red.parts))   # voxels whose reduce is already under way
+                    if k is not None:
+                        ev[k][0].record()                                    # the last chunk is done: from here on the reduce is exposed
+                    red.finish(cev[-1])
+                    if k is not None:
+                        ev[k][1].record()
+                        overlap_info.update(share_of_grid_reduced_under_the_march=early / float(nvox),
+                                            violated=bool(red.violated), axis_and_direction=red.choice)
+                    return
+            else:
+                _lib.check(lib.drrt_backtrace_f32(p(rif), nvox, res, n, p(xt), p(vt), p(dx), p(dv), h, ds, p(grad),
+                                                  p(st_a), p(ws), ws.numel(), aflags, stream))
             if use_dist:
                 if k is not None:
                     ev[k][0].record()
@@ -558,11 +600,34 @@ def run_rank(args) -> int:
 
         def avg(name):
             v = [ms for k, ms in prof if k == name]
+            if name == "backtrace" and K > 1:            # K launches per step: their sum
+                return (sum(v) / len(v) * K) if v else float("nan")
             return (sum(v) / len(v)) if v else float("nan")
+        chunking = None
+        if K > 1:
+            # Which part of the grid is final after each chunk?  The adjoint moves a ray by -ds * v per iteration: along the
+            # source axis every plane beyond the deepest still-marching ray (+ the upper tap) is final while no ray heads back.
+            from adjointnonlinearraytracing_amd import drrt as _drrt
+            ax = {"x": 0, "y": 1, "z": 2}[args.source_axis]
+            fin = []
+            for c in range(K):
+                pr = _drrt.decode_chunk_progress(cprog[c])
+                if pr["active"] == 0:
+                    fin.append(1.0)
+                elif pr["vel_min"][ax] > 0.0:
+                    top = int(pr["pos_max"][ax] / h) + 2                   # first final plane
+                    fin.append(max(0.0, min(1.0, (R - top) / R)))
+                else:
+                    fin.append(0.0)
+            chunking = {"chunks": K, "iteration_bounds": cb, "grid_final_after_chunk": fin,
+                        "note": "share of the grid planes along the source axis that no still-marching ray can reach after "
+                                "chunk k (drrt_backtrace_chunk_f32 progress block); the slab-wise all-reduce of dist.py may "
+                                "start on that share while chunk k + 1 marches"}
         out = dict(n=n, steps=steps, elapsed=elapsed, fwd_total=fwd_total, adj_total=adj_total, fwd_steps=fwd_steps,
                    adj_steps=adj_steps, n_failed=n_failed, ms_fwd=avg("trace"), ms_adj=avg("backtrace"),
                    ms_sort=avg("sort"), ms_zero=avg("zero"), ms_quad=avg("quad"), ms_allreduce=ms_ar, pair=pair,
-                   pos=pos, vel=vel, flags=(fflags, aflags, pair), dbg=dbg, adjoint_kernel=choice)
+                   pos=pos, vel=vel, flags=(fflags, aflags, pair), dbg=dbg, adjoint_kernel=choice, chunking=chunking,
+                   overlap=(overlap_info if (K > 1 and use_dist and args.overlap_reduce) else None))
         if keep:                                   # results of the LAST step (the adjoint's grid holds this rank's gradient
             out.update(xt=xt, vt=vt,               # only when there is no all-reduce: parity_check runs at world == 1)
                        grad=grad.clone())
@@ -666,6 +731,7 @@ def run_rank(args) -> int:
         ach_fwd = fwd_steps * B_FWD / (ms_fwd * 1e-3) / 1e9
         default_cfg = (R == 256 and n == 1024 * 1024 and world == 1 and not args.no_sort and not args.direct_atomics
                        and not args.experiment and args.pair == "auto" and not args.fwd_flags and not args.shard_of
+                       and not args.adjoint_chunks
                        and not args.adj_flags and args.workload == "metric" and args.source_axis == "y")
         pmc, pmc_src = load_pmc() if default_cfg else (None, None)
         pk_adj = pmc_kernel(pmc, "drrt::k_backtrace_flat", "drrt::k_backtrace_win")
@@ -721,16 +787,18 @@ def run_rank(args) -> int:
                        "sort_rays": not args.no_sort, "pair_grid": bool(m["pair"]),
                        "parallelism": f"ray-shard x{world}", "backend": args.backend if use_dist else None,
                        "shard_of": args.shard_of or None, "shard_index": args.shard_index if args.shard_of else None,
-                       "adjoint_kernel": m["adjoint_kernel"]},
+                       "adjoint_kernel": m["adjoint_kernel"], "adjoint_chunks": args.adjoint_chunks or None},
             "roofline": roof,
             "roofline_fwd": roof_f,
             "phase_ms": {"sort_avg": m["ms_sort"], "zero_grid": m["ms_zero"],
                          "pair_copy": None if m["ms_quad"] != m["ms_quad"] else m["ms_quad"],
                          "trace": ms_fwd, "backtrace": ms_adj, "allreduce": m["ms_allreduce"] if use_dist else None,
-                         # the reduce starts when the adjoint has finished and nothing runs beside it: all of it is exposed
-                         # (the gradient of ANY ray subset is a full grid, so reducing half A under the
-                         # adjoint of half B doubles the bytes on the wire and cannot shorten the step)
-                         "allreduce_exposed": m["ms_allreduce"] if use_dist else None},
+                         # one whole-grid reduce after the adjoint: all of it is exposed.  With --adjoint-chunks K
+                         # --overlap-reduce (plane-source sets) the planes that are final after each chunk are reduced on a
+                         # side stream under the next chunk; `allreduce_exposed` is then what remains after the last chunk and
+                         # `allreduce` the same
+                         "allreduce_exposed": m["ms_allreduce"] if use_dist else None,
+                         "allreduce_overlapped": bool(m.get("overlap") is not None)},
             "fwd_only_ray_steps_per_s_per_gpu": fwd_steps / (ms_fwd * 1e-3),
             # the whole step's algorithmic bytes (32 B per forward + 64 B per adjoint ray-step) per second over
             # the HBM peak: above 1 means SURVEY's byte model is exhausted as a yardstick (the taps are cache-served) --
@@ -738,6 +806,10 @@ def run_rank(args) -> int:
             "whole_step_algorithmic_over_peak": (fwd_steps * B_FWD + adj_steps * B_ADJ) / (m["elapsed"] / args.steps)
                                                 / 1e9 / HBM_PEAK_GBS,
         }
+        if m.get("chunking"):
+            out["chunking"] = m["chunking"]
+        if m.get("overlap"):
+            out["overlap"] = m["overlap"]
         if "weak" in results and main_mode != "weak":
             w = results["weak"]
             out["weak_scaling"] = {"value": w["fwd_total"] * args.steps / w["elapsed"], "unit": "ray-steps/s",

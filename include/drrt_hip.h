@@ -285,6 +285,35 @@ DRRT_API int drrt_backtrace_f16io(const float* rif, long long nvox, const int re
                          drrt_stats* stats, void* workspace, size_t workspace_bytes,
                          unsigned flags, void* stream);
 
+/* Tracer::backtrace in depth chunks (not in the reference; for the multi-GPU path): the iterations
+ * [it_begin, it_begin + it_count) of the adjoint march's max_steps (drrt_backtrace_max_steps(); it_count < 0 = all that are
+ * left), same arguments as drrt_backtrace_f32.  it_begin == 0 starts from (xt, vt, dx, dv) and zeroes `grad` (unless
+ * DRRT_FLAG_NO_ZERO) and `stats`; it_begin > 0 continues from `state` (drrt_backtrace_chunk_state_bytes(n) bytes, written
+ * by the previous chunk; opaque) and accumulates into `grad` and `stats`.  After the last chunk `grad` holds what
+ * drrt_backtrace_f32 computes -- the same per-ray contributions, summed in another order.  Why: with rays that travel on
+ * one clock (a plane source) the part of the grid every ray has left behind is FINAL after a chunk, so a rank can start
+ * reducing that slab with the other ranks while its next chunk marches (adjointnonlinearraytracing_amd/dist.py).
+ *   visit order  every chunk of a march must visit the rays in the SAME order (the state is stored per visit slot): with
+ *                DRRT_FLAG_SORT_RAYS hand the order of the first chunk (drrt_last_order(), or the paired forward's) to
+ *                every later chunk with drrt_set_order_hint(); a resumed chunk without it is refused.
+ *   progress     nullable DEVICE pointer to 20 ints, written by the chunk: where the rays that are still marching stand
+ *                and head -- [0..2] min and [3..5] max of their positions (x, y, z: the NEXT sample of each ray), [6..8] min
+ *                and [9..11] max of their velocities, as order-preserving keys (key = bits >= 0 ? bits : bits ^ 0x7fffffff;
+ *                the map is its own inverse), [12] their number -- and [13..15] min, [16..18] max of the positions of
+ *                the samples THIS chunk contributed at (a sample at p touches the voxels floor(p / h) and floor(p / h) + 1
+ *                per axis), [19] unused.  The march moves a ray by -ds * v per iteration: a half space that lies behind
+ *                every marching ray and that no ray heads back into is final; the sample box of the NEXT chunk tells
+ *                afterwards whether that held.
+ * Runs the box-window kernel (k_backtrace_flat) whatever the bundles look like; fp32 ray state only.                  */
+DRRT_API size_t drrt_backtrace_chunk_state_bytes(size_t n);
+DRRT_API int drrt_backtrace_max_steps(const int res[3], float h, float ds);      /* src/tracer.cpp:417 (Q5); < 0: bad arguments */
+DRRT_API int drrt_backtrace_chunk_f32(const float* rif, long long nvox, const int res[3], size_t n,
+                         const float* xt, const float* vt, const float* dx, const float* dv,
+                         float h, float ds, float* grad,
+                         drrt_stats* stats, void* workspace, size_t workspace_bytes,
+                         unsigned flags, void* stream,
+                         void* state, size_t state_bytes, int it_begin, int it_count, int* progress);
+
 /* Tracer::backtrace_sdf -- src/tracer.cpp:443-509, TracerC.backtrace_sdf (src/drrt.cpp:57).     */
 DRRT_API int drrt_backtrace_sdf_f32(const float* rif, const float* sdf, long long nvox, const int res[3],
                            size_t n, const float* xt, const float* vt,

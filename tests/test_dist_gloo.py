@@ -219,3 +219,123 @@ def test_world2_image_loss_on_ray_shards(tmp_path, oracle):
     assert float(np.load(tmp_path / "iloss_0.npy")) == pytest.approx(float(loss), rel=1e-9)
     assert cases.rel_l2(g0, rif.grad.numpy()) < 1e-5
     assert float(np.abs(g0).sum()) > 0
+
+
+# ---- slab-wise all-reduce under a depth-chunked adjoint (dist.SlabReducer) ----------------------------------------------
+def _prog(active, pos_lo, pos_hi, vel_lo, vel_hi, s_lo, s_hi):
+    return dict(active=active, pos_min=pos_lo, pos_max=pos_hi, vel_min=vel_lo, vel_max=vel_hi, sample_min=s_lo, sample_max=s_hi)
+
+
+def _slab_scenarios(rank, shape, h):
+    """Per scenario: the progress blocks this rank reports after each of 4 chunks.  The rays march towards -y (adjoint of a
+    +y plane source), rank 1 a little behind rank 0; shape = (D, H, W)."""
+    D, H, W = shape
+    top = (H - 1) * h
+    lag = 0.6 * h * rank
+    def down(k, turned=False, sample_hi=None):                  # after chunk k: the deepest marching ray stands at y_k
+        y_hi = top * (1.0 - 0.25 * (k + 1)) + lag
+        y_lo = max(0.0, y_hi - 1.5 * h)
+        prev_hi = top * (1.0 - 0.25 * k) + lag if k else top
+        vy = (-0.2, 1.0) if turned else (0.7, 1.0)
+        return _prog(50 if k < 3 else 0, [0.1, y_lo, 0.1], [0.9 * (W - 1) * h, y_hi, 0.9 * (D - 1) * h],
+                     [-.1, vy[0], -.1], [.1, vy[1], .1], [0.1, y_hi, 0.1],
+                     [0.9 * (W - 1) * h, prev_hi if sample_hi is None else sample_hi, 0.9 * (D - 1) * h])
+    def up_z(k):                                                # rays marching towards +z (v_z < 0)
+        zt = (D - 1) * h
+        z_lo = zt * 0.25 * (k + 1) - lag
+        prev = zt * 0.25 * k - lag if k else 0.0
+        return _prog(40 if k < 3 else 0, [0.1, 0.1, max(0.0, z_lo)], [0.5, 0.5, min(zt, z_lo + 1.2 * h)], [-.1, -.1, -1.0], [.1, .1, -0.6],
+                     [0.1, 0.1, max(0.0, prev)], [0.5, 0.5, min(zt, z_lo + 1.2 * h)])
+    return {
+        "down_y": [down(k) for k in range(4)],
+        "up_z": [up_z(k) for k in range(4)],
+        # a ray of rank 1 turns around in chunk 2: nothing more is handed in early, the rest goes at the end
+        "turned": [down(0), down(1), down(2, turned=(rank == 1)), down(3)],
+        # rank 0's third chunk contributes ABOVE planes that were handed in after chunk 1: the slab results must be dropped
+        "violated": [down(0), down(1), down(2, sample_hi=(top if rank == 0 else None)), down(3)],
+        # no axis on which all rays agree (a multi-view set): the plain whole-grid reduce
+        "no_axis": [_prog(30, [0, 0, 0], [.5, .5, .5], [-1, -1, -1], [1, 1, 1], [0, 0, 0], [.5, .5, .5])] * 4,
+    }
+
+
+def _slab_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from adjointnonlinearraytracing_amd import dist as D
+    D.init_from_env(backend="gloo")
+    shape, h = (7, 13, 9), 0.1                                   # (D, H, W): non-cubic on purpose
+    report = {}
+    for name, seq in _slab_scenarios(rank, shape, h).items():
+        g = torch.from_numpy(np.random.default_rng(100 + rank).normal(size=shape).astype(np.float32)).reshape(-1).clone()
+        want = g.clone(); dist.all_reduce(want)                 # the whole-grid reduce: the reference result
+        red = D.SlabReducer(g, shape, h)
+        for pr in seq:
+            red.after_chunk(pr)
+        early = sum(int(np.prod(b.shape)) for _, b, _ in red.parts)          # voxels handed in BEFORE the end
+        out = red.finish()
+        assert torch.equal(out, want), name                      # slab-wise == whole-grid, bit for bit (same two summands)
+        report[name] = dict(early=early, violated=red.violated, stopped=red.stopped, choice=red.choice)
+    np.save(os.path.join(out_dir, f"slab_{rank}.npy"), np.asarray([repr(report)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_slabwise_allreduce_equals_whole_grid_allreduce(tmp_path):
+    """dist.SlabReducer over gloo, world 2: whatever the ranks report -- planes final early, a ray that turns around, a
+    chunk that contributes into planes already handed in, no common axis -- every rank ends with exactly the whole-grid
+    all-reduce; and in the regular case most of the grid is reduced BEFORE the last chunk has finished."""
+    world, port = 2, 29911 + (os.getpid() % 60)
+    mp.spawn(_slab_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rep = [eval(str(np.load(tmp_path / f"slab_{r}.npy")[0])) for r in range(world)]
+    assert rep[0] == rep[1]                                      # the ranks agreed on every decision
+    r = rep[0]
+    nvox = 7 * 13 * 9
+    assert r["down_y"]["choice"] == (1, True) and r["down_y"]["early"] >= 0.6 * nvox and not r["down_y"]["violated"]
+    assert r["up_z"]["choice"] == (2, False) and r["up_z"]["early"] >= 0.5 * nvox
+    assert r["turned"]["stopped"] and 0 < r["turned"]["early"] < r["down_y"]["early"]
+    assert r["violated"]["violated"]
+    assert r["no_axis"]["choice"] is None and r["no_axis"]["early"] == 0
+
+
+def _chunked_standin(rif_flat, shape, xt, vt, gx, gv, h, ds, order, chunks, on_chunk):
+    """CPU stand-in for TracerC.backtrace_chunked: the oracle's adjoint in one go, then `chunks` progress reports of rays
+    marching down the y axis (the grid is complete from the start, so any slab partition must reproduce it)."""
+    g = _oracle_backtrace(rif_flat, shape, xt, vt, gx, gv, h, ds, order=order)
+    H = shape[1]
+    for k in range(chunks):
+        y_hi = (H - 1) * h * (1.0 - (k + 1) / chunks)
+        on_chunk(k, g, _prog(10 if k < chunks - 1 else 0, [0, max(0.0, y_hi - h), 0], [1, y_hi, 1], [-.1, .8, -.1], [.1, 1, .1],
+                             [0, y_hi, 0], [1, (H - 1) * h * (1.0 - k / chunks), 1]))
+    return g
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import cases
+    from adjointnonlinearraytracing_amd import dist as D
+    D.init_from_env(backend="gloo")
+    R, span = 17, 1.0
+    h = span / (R - 1); ds = h / 2
+    pos, vel = cases.plane_rays(400, span, ds, seed=2, axis=1, tilt=0.05)
+    pos, vel = torch.from_numpy(pos), torch.from_numpy(vel)
+    x, v = D.shard_rays(rank, world, pos, vel)
+    D._hip_trace, D._hip_backtrace = _oracle_trace, _oracle_backtrace
+    D._hip_backtrace_chunked, D._decode_progress = _chunked_standin, (lambda p: p)
+    grads = {}
+    for chunks in (0, 4):
+        rif = torch.from_numpy(cases.smooth_field(R, seed=5)).requires_grad_(True)
+        xt, vt = D.ShardedBackTracerC.apply(rif, x, v, h, ds, None, chunks)
+        ((xt ** 2).sum() + vt.sum()).backward()
+        grads[chunks] = rif.grad.numpy().copy()
+    assert np.array_equal(grads[0], grads[4])
+    np.save(os.path.join(out_dir, f"ov_{rank}.npy"), grads[4])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_sharded_tracer_with_overlapped_reduce(tmp_path, oracle):
+    """dist.ShardedBackTracerC(..., overlap_chunks=4) == the plain sharded tracer (one whole-grid all-reduce) on every rank."""
+    world, port = 2, 29711 + (os.getpid() % 90)
+    mp.spawn(_overlap_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert np.array_equal(np.load(tmp_path / "ov_0.npy"), np.load(tmp_path / "ov_1.npy"))

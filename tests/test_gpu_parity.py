@@ -831,6 +831,85 @@ def test_ring_window_with_rays_that_run_out_of_steps_beside_delayed_lanes(gpu, o
         assert cases.rel_l2(grads[name], grads["direct"]) <= 2e-5, name
 
 
+@pytest.mark.parametrize("sort", [True, False])
+def test_chunked_adjoint_equals_the_one_launch_adjoint(gpu, oracle, drrt_mod, sort):
+    """drrt_backtrace_chunk_f32 / TracerC.backtrace_chunked (include/drrt_hip.h): the adjoint march in K depth chunks --
+    state handed from launch to launch, every accumulator handed over and every window flushed at a chunk's end -- gives
+    the gradient of the one-launch march (same per-ray contributions; src/tracer.cpp:384-440) for K = 1, 3, 4, 7, with
+    equal step totals, and the progress block of every chunk is consistent with where the rays are."""
+    R, span = 33, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif_np = cases.luneburg(R)
+    rif = _t(rif_np, gpu)
+    pos, vel = cases.plane_rays(5000, span, ds, seed=7, axis=1, tilt=0.05)
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = sort
+    try:
+        xt, vt = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+        order = drrt_mod.keep_order(drrt_mod.last_order)
+        assert (order is not None) == sort
+        rng = np.random.default_rng(3)
+        dx = _t(rng.normal(size=pos.shape).astype(np.float32), gpu); dv = _t(rng.normal(size=pos.shape).astype(np.float32), gpu)
+        g_one = T.backtrace(rif, rif.shape, xt, vt, dx, dv, h, ds, order=order)
+        st_one = drrt_mod.read_stats()
+        with oracle.arith("factored"):
+            ob = oracle.backtrace(rif_np, rif_np.shape, xt.cpu().numpy(), vt.cpu().numpy(), dx.cpu().numpy(), dv.cpu().numpy(),
+                                  h, ds, dtype=np.float32)
+        assert st_one["ray_steps"] == ob["steps_total"]
+        for K in (1, 3, 4, 7):
+            seen = []
+            g = T.backtrace_chunked(rif, rif.shape, xt, vt, dx, dv, h, ds, order=order, chunks=K,
+                                    on_chunk=lambda k, grad, prog: seen.append(drrt_mod.decode_chunk_progress(prog)))
+            st = drrt_mod.read_stats()
+            assert st["ray_steps"] == ob["steps_total"], K
+            assert cases.rel_l2(g.cpu().numpy(), ob["grad"]) <= 2e-5, K
+            assert cases.rel_l2(g.cpu().numpy(), g_one.cpu().numpy()) <= 2e-5, K
+            assert len(seen) == K
+            # the rays travel towards -y in the adjoint: the deepest still-marching position can only move down, and every
+            # chunk's samples lie at or below the previous chunk's
+            ymax = [p["pos_max"][1] for p in seen if p["active"]]
+            assert all(b <= a + 1e-6 for a, b in zip(ymax, ymax[1:])), (K, ymax)
+            smax = [p["sample_max"][1] for p in seen if p["sample_max"] is not None]
+            assert all(b <= a + 1e-6 for a, b in zip(smax, smax[1:])), (K, smax)
+            assert seen[0]["sample_max"][1] <= float(xt[:, 1].max()) + 1e-6
+            assert seen[-1]["active"] == 0                   # every ray has left the volume well before max_steps
+    finally:
+        drrt_mod.options.sort_rays = True
+
+
+def test_chunked_adjoint_refuses_inconsistent_calls(gpu, drrt_mod):
+    """A resumed chunk of a sorted march without the visit order of its first chunk, a state buffer that is too small and
+    the one-atomic-per-tap mode are refused with a message (never a silently different gradient)."""
+    import ctypes as C
+    from adjointnonlinearraytracing_amd import _lib
+    lib = _lib.load()
+    R, n = 9, 300
+    h = 1.0 / (R - 1); ds = h / 2
+    rif = _t(cases.smooth_field(R, seed=1), gpu).reshape(-1).contiguous()
+    pos, vel = cases.plane_rays(n, 1.0, ds, seed=1, axis=1, tilt=0.0)
+    xt, vt = _t(pos, gpu), _t(vel, gpu)
+    n = xt.shape[0]
+    ones = torch.ones_like(xt)
+    res = (C.c_int * 3)(R, R, R)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, rif.numel(), 1)) + 1024, dtype=torch.uint8, device=gpu)
+    state = torch.empty(int(lib.drrt_backtrace_chunk_state_bytes(n)), dtype=torch.uint8, device=gpu)
+    g = torch.empty_like(rif)
+
+    def call(flags, it_begin, state_bytes=None):
+        return lib.drrt_backtrace_chunk_f32(p(rif), rif.numel(), res, n, p(xt), p(vt), p(ones), p(ones), h, ds, p(g), None,
+                                            p(ws), ws.numel(), flags, None, p(state),
+                                            state.numel() if state_bytes is None else state_bytes, it_begin, 4, None)
+    assert call(1, 0) == 0
+    assert call(1, 4) == _lib.ERR_ARG and b"visit order" in lib.drrt_last_error()
+    lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
+    assert call(1, 4) == 0
+    assert call(0, 0, state_bytes=16) == _lib.ERR_ARG and b"state buffer" in lib.drrt_last_error()
+    assert call(_lib.FLAG_DIRECT_ATOMICS, 0) == _lib.ERR_ARG
+    assert lib.drrt_backtrace_max_steps(res, h, ds) == int(np.float32(2.0) * np.float32(h) * np.float32(R) / np.float32(ds))
+    torch.cuda.synchronize()
+
+
 def test_q16_ray_state_mode(gpu, drrt_mod):
     """16-bit ray state "q16" (include/drrt_hip.h): trace_q16io / backtrace_q16io widen exactly, march in fp32 and round
     once -- trace_q16io(enc(x), enc(v)) == enc(trace_f32(dec(enc(x)), dec(enc(v)))) bit for bit, and the adjoint from
