@@ -29,6 +29,7 @@ FLAG_STATIC_WINDOW = 0x400000
 FLAG_CHORD_KEY = 0x800000
 FLAG_RING_WINDOW = 0x1000000
 FLAG_DISPATCH_IN_ORDER = 0x2000000
+FLAG_RING_SPARSE, FLAG_RING_GENERAL = 0x4000000, 0x8000000
 ADAM_MASK_BOUNDARY, ADAM_CLAMP_MIN = 1, 2
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
@@ -96,6 +97,7 @@ SIGNATURES = {
     "drrt_set_step_hint": (None, [_vp, _sz]),
     "drrt_last_bundle_counters": (_vp, []),
     "drrt_ring_threshold_pct": (_i, []),
+    "drrt_ring_sparse_threshold_pct": (_i, []),
     "drrt_profile_begin": (_i, [_i]),
     "drrt_profile_collect": (_i, [_vp, _vp, _i]),
     "drrt_profile_end": (None, []),

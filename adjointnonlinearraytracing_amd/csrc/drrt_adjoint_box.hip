@@ -176,20 +176,22 @@ __device__ __forceinline__ bool flat_emit8(win_t* win, int wsy, int wsz, float* 
 }
 
 __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
-  __shared__ unsigned s_cnt[4];                  // the block's four counters: one set of global atomics per block, not per wave
-  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+  __shared__ unsigned s_cnt[5];                  // the block's five counters: one set of global atomics per block, not per wave
+  if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0u;
   __syncthreads();
   const Vol& V = a.vol;
   const size_t t = (size_t)blockIdx.x * kClassifyStride * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   size_t i;
   bool ok = false;
-  int cx = 0, cy = 0, cz = 0;
+  int cx = 0, cy = 0, cz = 0, cbase = -1;
   if (ray_index(a.perm, t, a.n, i)) {
     const Ray3 p = ld3(a.xt, i, a.io_half, &a.vol, RAY_POS);
     const Cell c = locate(V, p.x, p.y, p.z);
-    cx = c.ix; cy = c.iy; cz = c.iz; ok = true;
+    cx = c.ix; cy = c.iy; cz = c.iz; cbase = c.base; ok = true;
   }
+  const int pbase = __builtin_amdgcn_update_dpp(-2, cbase, 0xB1, 0xF, 0xF, false);      // the pair partner's cell (quad_perm [1,0,3,2])
+  const unsigned paired = (unsigned)__popcll(__ballot(ok & (pbase == cbase)));
   const int big = 1 << 28;
   const int x0 = wave_min_i32(ok ? cx : big), x1 = wave_max_i32(ok ? cx : -big);
   const int y0 = wave_min_i32(ok ? cy : big), y1 = wave_max_i32(ok ? cy : -big);
@@ -209,9 +211,10 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
     atomicAdd(&s_cnt[1], 1u);
     if (outside) atomicAdd(&s_cnt[2], outside);
     atomicAdd(&s_cnt[3], lanes);
+    if (paired) atomicAdd(&s_cnt[4], paired);
   }
   __syncthreads();
-  if (threadIdx.x < 4 && s_cnt[threadIdx.x] != 0u) atomicAdd(&a.select[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x < 5 && s_cnt[threadIdx.x] != 0u) atomicAdd(&a.select[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 #ifndef DRRT_ANCHOR_SHIFT

@@ -59,6 +59,21 @@ namespace drrt {
                                     //   never sparse 9.9 / 5.9 / 5.0;  50 % -> 9.0 / 5.9 / 5.2;  70 % -> 8.9 / 6.8 / 5.7;  always sparse 8.9 / 8.8 / 5.9
 #endif
 constexpr int kRingCap = DRRT_RING_CAP;
+// Timing-only ablations of the PRODUCT instantiation (tools/build_variant.sh; the results of such a build are wrong by
+// construction and it is never shipped): -DDRRT_RING_T_NO_LDS drops the window adds, -DDRRT_RING_T_U32 makes them 32-bit
+// integer adds, -DDRRT_RING_T_NO_GLOBAL drops every global atomic, -DDRRT_RING_T_NO_FLUSH the flush loops.
+#if defined(DRRT_RING_T_NO_LDS)
+#define RING_ADD(q, v) ((void)0)
+#elif defined(DRRT_RING_T_U32)
+#define RING_ADD(q, v) atomicAdd(reinterpret_cast<unsigned*>(q), __float_as_uint(v))
+#else
+#define RING_ADD(q, v) atomicAdd((q), (win_t)(v))
+#endif
+#if defined(DRRT_RING_T_NO_GLOBAL)
+#define RING_GADD(g, v) ((void)0)
+#else
+#define RING_GADD(g, v) atomic_add_f32((g), (v))
+#endif
 // Diagnostic build only (-DDRRT_RING_STAMPS, tools/ring_stamps.py; never in the product library): wave-level s_memtime
 // brackets around the regions of an iteration, summed over the launch -- where a wave's TIME goes (issue + waiting), which
 // the PMC instruction counts cannot say.  Stamp values go to a buffer of their own that nothing else reads.
@@ -114,6 +129,9 @@ __device__ __forceinline__ int ring_locate(const Ring& R, int ix, int iy, int iz
 template <int A>
 __device__ __forceinline__ void ring_flush(win_t* win, const Ring& R, int g0, int k, float* __restrict__ grad, const Vol& V,
                                            int lane, bool no_global) {
+#if defined(DRRT_RING_T_NO_FLUSH)
+  return;
+#endif
   wave_lds_fence();
   const int e0 = A == 0 ? k : R.nx, e1 = A == 1 ? k : R.ny, e2 = A == 2 ? k : R.nz;
   const int e01 = e0 * e1, total = e01 * e2;
@@ -144,7 +162,7 @@ __device__ __forceinline__ void ring_flush(win_t* win, const Ring& R, int g0, in
     }
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
-      if (v[b] != (win_t)0 && !no_global) atomic_add_f32(grad + g[b], (float)v[b]);
+      if (v[b] != (win_t)0 && !no_global) RING_GADD(grad + g[b], (float)v[b]);
   }
   wave_lds_fence();
 }
@@ -186,13 +204,13 @@ __device__ __forceinline__ bool ring_cross(win_t* win, int experiment, bool pre,
       if (ABL && dbg) { ++ev_face; ev_add += add; }
       if (add) {
         win_t* q = win + qi;
-        atomicAdd(q, (win_t)(same ? s0 : (psame ? q0 : e0)));      atomicAdd(q + dP, (win_t)(same ? s1 : (psame ? q1 : e1)));
-        atomicAdd(q + dQ, (win_t)(same ? s2 : (psame ? q2 : e2))); atomicAdd(q + dQ + dP, (win_t)(same ? s3 : (psame ? q3 : e3)));
+        RING_ADD(q, (same ? s0 : (psame ? q0 : e0)));      RING_ADD(q + dP, (same ? s1 : (psame ? q1 : e1)));
+        RING_ADD(q + dQ, (same ? s2 : (psame ? q2 : e2))); RING_ADD(q + dQ + dP, (same ? s3 : (psame ? q3 : e3)));
       }
     } else {
       if (ABL && dbg) { ++ev_face; ++ev_add; }
       win_t* q = win + qi;
-      atomicAdd(q, (win_t)e0); atomicAdd(q + dP, (win_t)e1); atomicAdd(q + dQ, (win_t)e2); atomicAdd(q + dQ + dP, (win_t)e3);
+      RING_ADD(q, e0); RING_ADD(q + dP, e1); RING_ADD(q + dQ, e2); RING_ADD(q + dQ + dP, e3);
     }
   }
   // the new cell: one step along A in storage
@@ -204,11 +222,18 @@ __device__ __forceinline__ bool ring_cross(win_t* win, int experiment, bool pre,
   return (unsigned)(gA_new - oA) > (unsigned)(nA - 2);
 }
 
-template <bool ABL, bool PAIR, int MODE = 0>
+// SPARSE: the instantiation without the dense path (no per-axis crossings, no pair-partner sampling): every leave hands over
+//         all eight corners.  Chosen per CALL on the device (bundles_want_sparse: few lanes share their start cell with their
+//         pair partner) for ray sets like the reference's six rotated views, where the per-wave rule of the general
+//         instantiation settles on "sparse" for three quarters of the lane-steps anyway -- compiled without the dense
+//         code the same march runs 4-9 % faster (six rotated views 8.49 -> 8.13 ms, the same views through the weak
+//         medium 5.86 -> 5.31 ms, same box, round 4); dense multi-sample views keep the general instantiation (one 45-degree
+//         view at 4 samples per pixel: 7.2 ms against 9.6 ms sparse-only).
+template <bool ABL, bool PAIR, int MODE = 0, bool SPARSE = false>
 __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(BackArgs a) {
   if (a.select != nullptr) {                                 // launched next to k_backtrace_flat: the bundle
-    const bool want_fit = bundles_want_ring(a.select);                                // classification picks one of the two
-    if (!want_fit) return;
+    const bool want_fit = bundles_want_ring(a.select);                                // classification picks one of the three
+    if (!want_fit || bundles_want_sparse(a.select) != SPARSE) return;
   }
   __shared__ win_t s_win[kAdjWavesPerBlock][kRingCap];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
@@ -302,7 +327,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
   // blocks, which for rays oblique to the grid all run on every step (measured on the six rotated views: 535 -> 382 VALU
   // instructions per wave-step, 10.5 -> 8.9 ms; on the metric's dense bundles the same choice costs 6.4 -> 8.8 ms).
   const bool pre = true;
-  bool sparse = DRRT_RING_SIMPLE != 0;
+  bool sparse = SPARSE || DRRT_RING_SIMPLE != 0;
   unsigned ev_face = 0, ev_add = 0, ev_glob = 0, ev_all8 = 0, ev_wsteps = 0, ev_multi = 0;
   unsigned ev_nofit = 0, ev_service = 0, ev_left = 0, ev_vol = 0, ev_all8g = 0, ev_nopre = 0;   // debug: see the end of the kernel
 
@@ -314,19 +339,19 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
         const int dY = csy == R.ny - 1 ? -(R.ny - 1) * R.sy : R.sy;
         const int dZ = csz == R.nz - 1 ? -(R.nz - 1) * R.sz : R.sz;
         win_t* q = win + li;
-        atomicAdd(q, (win_t)p00.x);             atomicAdd(q + dX, (win_t)p00.y);
-        atomicAdd(q + dY, (win_t)p10.x);        atomicAdd(q + dY + dX, (win_t)p10.y);
-        atomicAdd(q + dZ, (win_t)p01.x);        atomicAdd(q + dZ + dX, (win_t)p01.y);
-        atomicAdd(q + dZ + dY, (win_t)p11.x);   atomicAdd(q + dZ + dY + dX, (win_t)p11.y);
+        RING_ADD(q, p00.x);             RING_ADD(q + dX, p00.y);
+        RING_ADD(q + dY, p10.x);        RING_ADD(q + dY + dX, p10.y);
+        RING_ADD(q + dZ, p01.x);        RING_ADD(q + dZ + dX, p01.y);
+        RING_ADD(q + dZ + dY, p11.x);   RING_ADD(q + dZ + dY + dX, p11.y);
       }
       return true;
     }
     if (experiment != 2) {
       float* g = a.grad + cbase;
-      atomic_add_f32(g, p00.x);                atomic_add_f32(g + 1, p00.y);
-      atomic_add_f32(g + V.sy, p10.x);         atomic_add_f32(g + V.sy + 1, p10.y);
-      atomic_add_f32(g + V.sz, p01.x);         atomic_add_f32(g + V.sz + 1, p01.y);
-      atomic_add_f32(g + V.sz + V.sy, p11.x);  atomic_add_f32(g + V.sz + V.sy + 1, p11.y);
+      RING_GADD(g, p00.x);                RING_GADD(g + 1, p00.y);
+      RING_GADD(g + V.sy, p10.x);         RING_GADD(g + V.sy + 1, p10.y);
+      RING_GADD(g + V.sz, p01.x);         RING_GADD(g + V.sz + 1, p01.y);
+      RING_GADD(g + V.sz + V.sy, p11.x);  RING_GADD(g + V.sz + V.sy + 1, p11.y);
     }
     return false;
   };
@@ -497,7 +522,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
       }
     }
     STAMP(1)                                                                  // window service
-    if (DRRT_RING_SIMPLE == 0 && (it & 15) == 15) {          // a sample of one iteration in 16 (scalar arithmetic only)
+    if (!SPARSE && DRRT_RING_SIMPLE == 0 && (it & 15) == 15) {   // a sample of one iteration in 16 (scalar arithmetic only)
       const bool on = s.active & regular;
       const int pb = __builtin_amdgcn_update_dpp(-1, base, 0xB1, 0xF, 0xF, false);   // the pair partner's cell (quad_perm [1,0,3,2])
       const int lanes = __popcll(__ballot(on)), hits = __popcll(__ballot(on & (pb == base)));
@@ -540,7 +565,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
         const bool old_regular = regular;
         int nbase; bool nregular;
         int dpack = -1;                                    // the move in cells, one VGPR: (ddx + 1) | (ddy + 1) << 2 | (ddz + 1) << 4, or -1
-        if (sparse) {                                      // (wave-uniform) a sparse bundle does not look at the move
+        if (SPARSE || sparse) {                            // (wave-uniform) a sparse bundle does not look at the move
           step_locate(nbase, nregular);
         } else {
           const int oix = ix, oiy = iy, oiz = iz;
@@ -567,7 +592,7 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
             if (old_regular) {
               const bool unit = dpack >= 0;
               const int ddx = (dpack & 3) - 1, ddy = ((dpack >> 2) & 3) - 1, ddz = ((dpack >> 4) & 3) - 1;
-              if (!sparse && (regular & unit & (old_lidx >= 0) & (experiment != 1) & (experiment != 4))) {
+              if (!SPARSE && !sparse && (regular & unit & (old_lidx >= 0) & (experiment != 1) & (experiment != 4))) {
                 // one, two or three faces crossed: one crossing after the other (x, y, z), each emits the face left behind
                 // and carries the shared one; the later ones hand over zeros where the earlier ones cleared
                 if (ABL && dbg) {
@@ -654,6 +679,11 @@ __global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(B
 }
 
 // ---- launcher -----------------------------------------------------------------------------------
+void launch_backtrace_ring_sparse(const BackArgs& a, hipStream_t s) {      // backtrace only (MODE 0)
+  const dim3 g(adj_grid_for(a.n)), b(kAdjBlock);
+  if (a.vol.pair != nullptr) hipLaunchKernelGGL((k_backtrace_ring<false, true, 0, true>), g, b, 0, s, a);
+  else                       hipLaunchKernelGGL((k_backtrace_ring<false, false, 0, true>), g, b, 0, s, a);
+}
 void launch_backtrace_ring(int mode, bool abl, const BackArgs& a, hipStream_t s) {
   const dim3 g(adj_grid_for(a.n)), b(kAdjBlock);
   const bool pair = a.vol.pair != nullptr;

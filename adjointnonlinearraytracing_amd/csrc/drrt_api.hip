@@ -63,6 +63,7 @@ extern "C" void drrt_set_step_hint(const uint32_t* steps, size_t n) { g_hint_ste
 static thread_local const unsigned* g_last_counters = nullptr;   // bundle classification of the last adjoint call (device, in its workspace)
 extern "C" const unsigned* drrt_last_bundle_counters(void) { return g_last_counters; }
 extern "C" int drrt_ring_threshold_pct(void) { return DRRT_RING_MIN_NOFIT_PCT; }
+extern "C" int drrt_ring_sparse_threshold_pct(void) { return DRRT_RING_SPARSE_MAX_PAIR_PCT; }
 
 // ---- optional per-kernel timing (bench / profiling aid; not thread-safe) --------------------
 // Event pairs are recorded on the call's stream right around a kernel launch; nothing
@@ -499,12 +500,18 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
       if (!force_box && !force_ring && a.perm != nullptr && ws && ws_bytes >= ctr_off + 512) {
         a.select = (unsigned*)((char*)ws + ctr_off + 256);
         g_last_counters = a.select;
-        hipError_t e = hipMemsetAsync(a.select, 0, 16, s);
+        hipError_t e = hipMemsetAsync(a.select, 0, 32, s);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(select)");
+        // [5] != 0 pins the general instantiation of the ring kernel: backtrace_sdf, the ablation / counter build and
+        // DRRT_FLAG_RING_GENERAL (A-B) have no sparse-only one
+        const bool sparse_ok = MODE == 0 && !abl && !(flags & DRRT_FLAG_RING_GENERAL);
+        if (!sparse_ok) { e = hipMemsetAsync((char*)a.select + 20, 1, 1, s); if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(select)"); }
         launch_bundle_classify(a, s);
+        if (sparse_ok) launch_backtrace_ring_sparse(a, s);
       }
       if (!force_ring) launch_backtrace_box(MODE, abl, a, s);
-      if (force_ring || a.select != nullptr) launch_backtrace_ring(MODE, abl, a, s);
+      if (force_ring && (flags & DRRT_FLAG_RING_SPARSE) && MODE == 0 && !abl) launch_backtrace_ring_sparse(a, s);
+      else if (force_ring || a.select != nullptr) launch_backtrace_ring(MODE, abl, a, s);
     }
   }
   LAUNCH_CHECK("k_backtrace");

@@ -325,7 +325,8 @@ __device__ __forceinline__ float quad_sum(float v) {
 // consecutive visit slots), every 16th block of bundles:
 //   [0] += 1 when the bounding box of the rays' start cells does not fit the default box window, [1] += 1 per bundle;
 //   [2] += the lanes whose start cell lies more than kClassifyReach cells (on any axis) from the bundle's mean cell,
-//          [3] += the lanes (diagnostic only: it does NOT predict which kernel is faster, see below).
+//          [3] += the lanes (diagnostic only: it does NOT predict which kernel is faster, see below);
+//   [4] += the lanes whose pair partner (lane ^ 1) starts in the same cell (dense sampling: see bundles_want_sparse).
 // k_backtrace_flat and k_backtrace_ring read the counters (bundles_want_ring): one of them runs.
 // Calibration (tools/probe_classify.py, 256^3, 1M rays unless noted; share of bundles not fitting -> box / ring kernel ms):
 //   metric 4 % -> 4.6 / 6.3; shifted plane 5 % -> 4.7 / 6.4; one view at 0 / 20 / 45 degrees through a weak lens 0 / 13 / 2 %
@@ -341,6 +342,16 @@ constexpr int kClassifyReach = 3;            // 9 slots = 8 cells: the mean cell
 #endif
 __device__ __forceinline__ bool bundles_want_ring(const unsigned* __restrict__ sel) {
   return sel[0] * 100u >= sel[1] * (unsigned)DRRT_RING_MIN_NOFIT_PCT && sel[0] != 0u;
+}
+// ... and which instantiation of the ring kernel: [4] = sampled lanes whose pair partner (lane ^ 1) starts in the same cell.
+// Few of them -> the sparse-only instantiation (k_backtrace_ring<..., SPARSE = true>).  Calibration (round 4, same box,
+// tools/probe_ring_sets.py; share of such lanes -> general / sparse-only instantiation, ms): see NOTES.md.
+// sel[5] != 0 (set by the host for backtrace_sdf and the A-B flags) pins the general instantiation.
+#ifndef DRRT_RING_SPARSE_MAX_PAIR_PCT
+#define DRRT_RING_SPARSE_MAX_PAIR_PCT 35
+#endif
+__device__ __forceinline__ bool bundles_want_sparse(const unsigned* __restrict__ sel) {
+  return sel[5] == 0u && sel[4] * 100u < sel[3] * (unsigned)DRRT_RING_SPARSE_MAX_PAIR_PCT;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,6 +382,7 @@ void launch_backtrace_direct(int mode, const BackArgs& a, hipStream_t s);
 void launch_bundle_classify(const BackArgs& a, hipStream_t s);
 void launch_backtrace_box(int mode, bool abl, const BackArgs& a, hipStream_t s);
 void launch_backtrace_ring(int mode, bool abl, const BackArgs& a, hipStream_t s);
+void launch_backtrace_ring_sparse(const BackArgs& a, hipStream_t s);       // the sparse-only instantiation (backtrace)
 // cable (drrt_cable.hip)
 void launch_trace_cable(const CableArgs& a, hipStream_t s);
 void launch_backtrace_cable(const CableArgs& a, hipStream_t s);

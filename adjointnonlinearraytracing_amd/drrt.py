@@ -36,7 +36,9 @@ class Options:
                                   # sync per call; the message may appear one call late -- see flush_warnings())
     direct_atomics: bool = False  # adjoint: one global atomic per tap (debug / A-B)
     adjoint_window: str = "auto"  # adjoint: "auto" = the bundles of the call are classified on the device and the box-window kernel
-                                  # (k_backtrace_flat) or the ring-window kernel (k_backtrace_ring) runs; "box" / "ring" force one
+                                  # (k_backtrace_flat) or the ring-window kernel (k_backtrace_ring; its general or its
+                                  # sparse-only instantiation) runs; "box" / "ring" / "ring_sparse" force one, "ring_general"
+                                  # keeps the choice but never takes the sparse-only instantiation (A-B)
     chord_key: bool = False       # locality sort with the rounds-1/2 key (DRRT_FLAG_CHORD_KEY, A-B)
     pair_grid: object = "auto"    # the "pair copy" of the grid in the workspace (DRRT_FLAG_PAIR_GRID; 8 bytes per voxel, two
                                   # 16-byte gathers per cell instead of four 8-byte ones).  True, False, or "auto" = a
@@ -109,6 +111,10 @@ def _flags(adjoint: bool = False) -> int:
         f |= _lib.FLAG_STATIC_WINDOW
     if adjoint and _opt().adjoint_window == "ring":
         f |= _lib.FLAG_RING_WINDOW
+    if adjoint and _opt().adjoint_window == "ring_sparse":       # A-B: the ring kernel's sparse-only instantiation, forced
+        f |= _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE
+    if adjoint and _opt().adjoint_window == "ring_general":      # A-B: device-side choice between box and the GENERAL ring kernel
+        f |= _lib.FLAG_RING_GENERAL
     if _opt().chord_key:
         f |= _lib.FLAG_CHORD_KEY
     if adjoint and _EXPERIMENT:
@@ -323,8 +329,8 @@ def _capture_counters(ws: torch.Tensor) -> None:
     if not ptr:
         return
     off = int(ptr) - ws.data_ptr()
-    if 0 <= off and off + 16 <= ws.numel():
-        last_bundle_counters = ws[off:off + 16].view(torch.int32).clone()
+    if 0 <= off and off + 32 <= ws.numel():
+        last_bundle_counters = ws[off:off + 32].view(torch.int32).clone()
 
 
 def read_bundle_counters() -> Optional[Dict[str, int]]:
@@ -336,8 +342,11 @@ def read_bundle_counters() -> Optional[Dict[str, int]]:
     c = [int(v) for v in last_bundle_counters.cpu()]
     share = c[0] / c[1] if c[1] else 0.0
     pct = int(_lib.load().drrt_ring_threshold_pct())
+    ring = bool(c[0] and c[0] * 100 >= c[1] * pct)
+    sparse = ring and c[5] == 0 and c[4] * 100 < c[3] * int(_lib.load().drrt_ring_sparse_threshold_pct())
     return dict(bundles_not_fitting=c[0], bundles=c[1], lanes_outside=c[2], lanes=c[3], not_fitting_share=share,
-                ring_threshold_pct=pct, kernel="ring" if (c[0] and c[0] * 100 >= c[1] * pct) else "box")
+                lanes_sharing_cell_with_pair_partner=c[4], pair_share=(c[4] / c[3] if c[3] else 0.0),
+                ring_threshold_pct=pct, kernel=("ring_sparse" if sparse else "ring") if ring else "box")
 
 
 def decode_chunk_progress(progress: torch.Tensor) -> Dict[str, object]:

@@ -490,6 +490,7 @@ def run_rank(args) -> int:
         torch.cuda.synchronize(dev)
 
     ring_pct = int(lib.drrt_ring_threshold_pct())
+    sparse_pct = int(lib.drrt_ring_sparse_threshold_pct())
 
     def bench_rays(pos, vel, steps, warmup, force_flags=None, keep=False, rif=rif):
         """Time `steps` fwd + adjoint passes over the rays (pos, vel) resident on the device; -> this rank's measurements.
@@ -585,11 +586,14 @@ def run_rank(args) -> int:
         cptr = lib.drrt_last_bundle_counters()
         if cptr:
             off = int(cptr) - ws.data_ptr()
-            if 0 <= off and off + 16 <= ws.numel():
-                c = ws[off:off + 16].view(torch.int32).cpu().tolist()
-                choice = {"kernel": "ring" if (c[0] and c[0] * 100 >= c[1] * ring_pct) else "box",
+            if 0 <= off and off + 32 <= ws.numel():
+                c = ws[off:off + 32].view(torch.int32).cpu().tolist()
+                ring = bool(c[0] and c[0] * 100 >= c[1] * ring_pct)
+                sparse = ring and c[5] == 0 and c[4] * 100 < c[3] * sparse_pct
+                choice = {"kernel": ("ring_sparse" if sparse else "ring") if ring else "box",
                           "bundles_not_fitting": c[0], "bundles_sampled": c[1], "ring_threshold_pct": ring_pct,
-                          "lanes_far_from_bundle": c[2], "lanes_sampled": c[3]}
+                          "lanes_far_from_bundle": c[2], "lanes_sampled": c[3],
+                          "lanes_sharing_cell_with_pair_partner": c[4], "sparse_max_pair_pct": sparse_pct}
         t = torch.tensor([elapsed, float(fwd_steps), float(adj_steps)], dtype=torch.float64, device=dev)
         if use_dist:
             tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -83,6 +83,9 @@ extern "C" {
  * kernel (compact bundles) or the ring-window kernel (sparse views, views oblique to the grid) runs; the two flags force one. */
 #define DRRT_FLAG_RING_WINDOW 0x1000000u   /* backtrace, backtrace_sdf: always the ring-window kernel (k_backtrace_ring: the wave's LDS window is
                                               addressed modulo its size and follows the rays; each voxel is flushed once; honours the step hint) */
+#define DRRT_FLAG_RING_SPARSE  0x4000000u  /* with RING_WINDOW (A-B): the sparse-only instantiation of the ring-window kernel (every cell
+                                              leave hands over all eight corners; chosen by itself for sparse ray sets) */
+#define DRRT_FLAG_RING_GENERAL 0x8000000u  /* backtrace (A-B): never the sparse-only instantiation (the per-wave dense / sparse rule only) */
 #define DRRT_FLAG_STATIC_WINDOW 0x400000u  /* backtrace, backtrace_sdf: always the box-window kernel (k_backtrace_flat, compile-time 9^3 gradient
                                               windows), no per-call bundle classification */
 #define DRRT_FLAG_DISPATCH_IN_ORDER 0x2000000u /* trace, trace_pln, backtrace, backtrace_sdf (A-B measurement; forward bit-identical, adjoint the same
@@ -172,12 +175,16 @@ DRRT_API void drrt_set_step_hint(const uint32_t* steps, size_t n);
  * workspace: valid while the workspace is, read it after synchronising the stream), or NULL when that call did not (no visit
  * order, a forced kernel, a workspace without the counter block).  Over every 16th block of 64-ray bundles:
  *   [0] bundles whose start cells do not fit the box window, [1] bundles looked at,
- *   [2] lanes whose start cell lies more than 3 cells from their bundle's mean cell, [3] lanes looked at (diagnostic).
+ *   [2] lanes whose start cell lies more than 3 cells from their bundle's mean cell, [3] lanes looked at (diagnostic),
+ *   [4] lanes whose pair partner (lane ^ 1) starts in the same cell, [5] non-zero when the call pinned the general
+ *   instantiation of the ring kernel (8 ints in all; [6], [7] unused).  The ring kernel's sparse-only instantiation runs
+ *   when [4] * 100 < [3] * 35 (few rays per cell column: every cell leave hands over all eight corners).
  * The ring-window kernel runs when [0] * 100 >= [1] * drrt_ring_threshold_pct() (the library's compile-time threshold, 20 in
  * the product build; calibration: csrc/drrt_march.h, bundles_want_ring).  The counters describe the START cells of the
  * bundles (the exit rays as given), not where the step hint's delays put the lanes later on. */
 DRRT_API const unsigned* drrt_last_bundle_counters(void);
 DRRT_API int drrt_ring_threshold_pct(void);
+DRRT_API int drrt_ring_sparse_threshold_pct(void);      /* the 35 of "[4] * 100 < [3] * 35" below, as compiled */
 
 /* ---- 16-bit ray state "q16" (BASELINE.json config 5: "fp16 ray state + fp32 adjoint accumulate") -----------------
  * The reference is fp32-only (include/types.h:36-46).  IEEE half keeps 11 significant bits wherever the value is:

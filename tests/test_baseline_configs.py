@@ -536,4 +536,4 @@ def test_bench_workloads_against_the_oracle_at_full_size(gpu, oracle, D, workloa
     print(workload, c)
     assert c is not None
     if workload != "tomo_weak":           # (the weak medium's straight rays sit between the two regimes: either kernel is right)
-        assert c["kernel"] == ("box" if workload == "metric" else "ring"), c
+        assert c["kernel"] == ("box" if workload == "metric" else "ring_sparse"), c      # ~2 rays per cell column: sparse-only

@@ -54,9 +54,6 @@ drrt.options.sort_rays = True
 drrt.options.pair_grid = False
 probe("4 views, no pair copy", xs, vs)
 drrt.options.pair_grid = "auto"
-drrt.options.legacy_adjoint = True
-probe("4 views, legacy adjoint kernel (10^3 windows)", xs, vs)
-drrt.options.legacy_adjoint = False
 with drrt.using(adjoint_window="box"):
     probe("4 views, box-window adjoint kernel forced", xs, vs)
 with drrt.using(adjoint_window="ring"):
