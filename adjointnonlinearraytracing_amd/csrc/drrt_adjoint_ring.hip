@@ -58,7 +58,6 @@ namespace drrt {
                                     // on: six rotated views / metric / 4-view tomography set (tools/probe_views.py):
                                     //   never sparse 9.9 / 5.9 / 5.0;  50 % -> 9.0 / 5.9 / 5.2;  70 % -> 8.9 / 6.8 / 5.7;  always sparse 8.9 / 8.8 / 5.9
 #endif
-constexpr int kRingCap = DRRT_RING_CAP;
 // Timing-only ablations of the PRODUCT instantiation (tools/build_variant.sh; the results of such a build are wrong by
 // construction and it is never shipped): -DDRRT_RING_T_NO_LDS drops the window adds, -DDRRT_RING_T_U32 makes them 32-bit
 // integer adds, -DDRRT_RING_T_NO_GLOBAL drops every global atomic, -DDRRT_RING_T_NO_FLUSH the flush loops.
@@ -223,17 +222,24 @@ __device__ __forceinline__ bool ring_cross(win_t* win, int experiment, bool pre,
 }
 
 // SPARSE: the instantiation without the dense path (no per-axis crossings, no pair-partner sampling): every leave hands over
-//         all eight corners.  Chosen per CALL on the device (bundles_want_sparse: few lanes share their start cell with their
-//         pair partner) for ray sets like the reference's six rotated views, where the per-wave rule of the general
+//         all eight corners.  Chosen per CALL on the device (bundles_want_sparse: few neighbours of the visit order share
+//         their transverse cell) for ray sets like the reference's six rotated views, where the per-wave rule of the general
 //         instantiation settles on "sparse" for three quarters of the lane-steps anyway -- compiled without the dense
 //         code the same march runs 4-9 % faster (six rotated views 8.49 -> 8.13 ms, the same views through the weak
 //         medium 5.86 -> 5.31 ms, same box, round 4); dense multi-sample views keep the general instantiation (one 45-degree
 //         view at 4 samples per pixel: 7.2 ms against 9.6 ms sparse-only).
+#ifndef DRRT_RING_SPARSE_WAVES
+#define DRRT_RING_SPARSE_WAVES DRRT_RING_WAVES      // (A-B: occupancy of the sparse-only instantiation)
+#endif
+#ifndef DRRT_RING_SPARSE_CAP
+#define DRRT_RING_SPARSE_CAP DRRT_RING_CAP
+#endif
 template <bool ABL, bool PAIR, int MODE = 0, bool SPARSE = false>
-__global__ void __launch_bounds__(kAdjBlock, DRRT_RING_WAVES) k_backtrace_ring(BackArgs a) {
+__global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : DRRT_RING_WAVES) k_backtrace_ring(BackArgs a) {
+  constexpr int kRingCap = SPARSE ? DRRT_RING_SPARSE_CAP : DRRT_RING_CAP;
   if (a.select != nullptr) {                                 // launched next to k_backtrace_flat: the bundle
     const bool want_fit = bundles_want_ring(a.select);                                // classification picks one of the three
-    if (!want_fit || bundles_want_sparse(a.select) != SPARSE) return;
+    if (!want_fit || bundles_want_sparse(a.select, a.order_stats) != SPARSE) return;
   }
   __shared__ win_t s_win[kAdjWavesPerBlock][kRingCap];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;

@@ -262,6 +262,7 @@ struct BackArgs {
   int experiment;              // development ablations (0 = product behaviour)
   unsigned* select;            // nullable (k_backtrace_flat): [0] waves a fitted window would help, [1] waves classified
   const uint32_t* fsteps;      // nullable: per-ray iteration counts of the forward march that produced (xt, vt) (step hint)
+  const uint32_t* order_stats; // nullable: the visit order's pair-sharing counters (drrt_sort.hip: k_order_pair_stats)
   int xcd_order;               // 1: the launch's blocks take the visit order XCD by XCD (xcd_block)
   // resumable march (drrt_backtrace_chunk_f32; k_backtrace_flat<..., CHUNK = true>): nullable
   float* chunk_state;          // 13 words per visit slot, SoA with stride chunk_stride: x, v, lambda, mu, flags
@@ -343,15 +344,26 @@ constexpr int kClassifyReach = 3;            // 9 slots = 8 cells: the mean cell
 __device__ __forceinline__ bool bundles_want_ring(const unsigned* __restrict__ sel) {
   return sel[0] * 100u >= sel[1] * (unsigned)DRRT_RING_MIN_NOFIT_PCT && sel[0] != 0u;
 }
-// ... and which instantiation of the ring kernel: [4] = sampled lanes whose pair partner (lane ^ 1) starts in the same cell.
-// Few of them -> the sparse-only instantiation (k_backtrace_ring<..., SPARSE = true>).  Calibration (round 4, same box,
-// tools/probe_ring_sets.py; share of such lanes -> general / sparse-only instantiation, ms): see NOTES.md.
-// sel[5] != 0 (set by the host for backtrace_sdf and the A-B flags) pins the general instantiation.
+// ... and which instantiation of the ring kernel.  The general one decides wave by wave, every 16 iterations, whether the
+// bundle is dense (at least half of the lanes share their cell with their pair partner: face carry-over + DPP pre-reduction)
+// or sparse (all eight corners handed over on every leave); the sparse-only one is compiled without the dense path and runs
+// the same sparse march 6-9 % faster.  Which of the two a CALL takes is decided from how densely the ray set samples the
+// volume, measured where the lens cannot distort it: in the space the locality sort works in.  ms[0] / ms[1] = the share of
+// pairs of neighbours (2 i, 2 i + 1) of the visit order that travel in the same direction cell through the same
+// grid-cell-sized cell of transverse offset (drrt_sort.hip: k_order_pair_stats; handed over with the order).  The START
+// cells of the adjoint cannot tell (k_bundle_classify's [4]: 0.56 for the six rotated views through the Luneburg ball, 0.49
+// for four dense tomography views -- the first is faster sparse-only, the second general), and sampling the forward march
+// itself cost that kernel 10-15 % (round 4, NOTES.md).  Without the counters, or with sel[5] != 0 (set by the host for
+// backtrace_sdf and the A-B flags), the general instantiation runs.
 #ifndef DRRT_RING_SPARSE_MAX_PAIR_PCT
-#define DRRT_RING_SPARSE_MAX_PAIR_PCT 35
+#define DRRT_RING_SPARSE_MAX_PAIR_PCT 80     // calibration (round 4, tools/probe_ring_sets.py, 256^3 / 1M rays; share -> general / sparse-only ms):
+                                             //   six rotated views 0.71 -> 8.32 / 7.83 (ball), 5.88 / 5.28 (weak medium); four tomography views
+                                             //   at 4 samples per pixel 0.87 -> 4.98 / 5.62 (blob), 7.32 / 7.11 (ball); one 45-degree view 0.94 ->
+                                             //   7.2 / 9.6; the metric's plane source 1.00
 #endif
-__device__ __forceinline__ bool bundles_want_sparse(const unsigned* __restrict__ sel) {
-  return sel[5] == 0u && sel[4] * 100u < sel[3] * (unsigned)DRRT_RING_SPARSE_MAX_PAIR_PCT;
+__device__ __forceinline__ bool bundles_want_sparse(const unsigned* __restrict__ sel, const uint32_t* __restrict__ ms) {
+  return ms != nullptr && sel[5] == 0u && ms[1] != 0u &&
+         (unsigned long long)ms[0] * 100ull < (unsigned long long)ms[1] * (unsigned long long)DRRT_RING_SPARSE_MAX_PAIR_PCT;
 }
 
 // ---------------------------------------------------------------------------------------------

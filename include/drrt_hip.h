@@ -170,21 +170,31 @@ DRRT_API size_t drrt_order_hint_pending(void);
 DRRT_API const uint32_t* drrt_last_steps(size_t* n_out);
 DRRT_API void drrt_set_step_hint(const uint32_t* steps, size_t n);
 
+/* How densely does the ray set sample the volume?  Every call that sorts its rays (light-field key) leaves two uint32
+ * counters next to the order (DEVICE pointer into that call's workspace; NULL when the last sorted call left none): [0] the
+ * pairs of neighbours (2 i, 2 i + 1) of the visit order that travel in the same direction cell through the same
+ * grid-cell-sized cell of transverse offset, [1] all pairs.  They belong to the ORDER: hand them over with it (same rules as
+ * the other hints: per thread, consumed by the next march call, speed only; ignored without a matching order hint).  The
+ * adjoint's ring-window kernel picks its instantiation from them: below drrt_ring_sparse_threshold_pct() % the sparse-only
+ * one.  Without them the general instantiation runs; an adjoint that sorts for itself uses its own. */
+DRRT_API const uint32_t* drrt_last_order_stats(void);
+DRRT_API void drrt_set_order_stats_hint(const uint32_t* stats2);
+
 /* Which adjoint kernel ran, and why: a DEVICE pointer to the four counters of the bundle classification of the last
  * drrt_backtrace_* / drrt_backtrace_sdf_f32 call on this host thread that classified its bundles (it lies in that call's
  * workspace: valid while the workspace is, read it after synchronising the stream), or NULL when that call did not (no visit
  * order, a forced kernel, a workspace without the counter block).  Over every 16th block of 64-ray bundles:
  *   [0] bundles whose start cells do not fit the box window, [1] bundles looked at,
  *   [2] lanes whose start cell lies more than 3 cells from their bundle's mean cell, [3] lanes looked at (diagnostic),
- *   [4] lanes whose pair partner (lane ^ 1) starts in the same cell, [5] non-zero when the call pinned the general
- *   instantiation of the ring kernel (8 ints in all; [6], [7] unused).  The ring kernel's sparse-only instantiation runs
- *   when [4] * 100 < [3] * 35 (few rays per cell column: every cell leave hands over all eight corners).
+ *   [4] lanes whose pair partner (lane ^ 1) starts in the same cell (diagnostic), [5] non-zero when the call pinned the
+ *   general instantiation of the ring kernel (8 ints in all; [6], [7] unused).  Which instantiation of the ring kernel runs
+ *   is decided from the visit order's pair-sharing counters (drrt_last_order_stats), not from these.
  * The ring-window kernel runs when [0] * 100 >= [1] * drrt_ring_threshold_pct() (the library's compile-time threshold, 20 in
  * the product build; calibration: csrc/drrt_march.h, bundles_want_ring).  The counters describe the START cells of the
  * bundles (the exit rays as given), not where the step hint's delays put the lanes later on. */
 DRRT_API const unsigned* drrt_last_bundle_counters(void);
 DRRT_API int drrt_ring_threshold_pct(void);
-DRRT_API int drrt_ring_sparse_threshold_pct(void);      /* the 35 of "[4] * 100 < [3] * 35" below, as compiled */
+DRRT_API int drrt_ring_sparse_threshold_pct(void);      /* sparse-only ring instantiation when order stats [0] * 100 < [1] * this */
 
 /* ---- 16-bit ray state "q16" (BASELINE.json config 5: "fp16 ray state + fp32 adjoint accumulate") -----------------
  * The reference is fp32-only (include/types.h:36-46).  IEEE half keeps 11 significant bits wherever the value is:

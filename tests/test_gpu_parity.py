@@ -910,6 +910,51 @@ def test_chunked_adjoint_refuses_inconsistent_calls(gpu, drrt_mod):
     torch.cuda.synchronize()
 
 
+def test_order_pair_stats_pick_the_ring_kernel_instantiation(gpu, oracle, drrt_mod):
+    """drrt_last_order_stats / drrt_set_order_stats_hint (include/drrt_hip.h): a sorted call leaves two counters next to its
+    visit order -- neighbours of the order that share direction cell and transverse cell / pairs looked at -- and the
+    adjoint's ring-window kernel takes its sparse-only instantiation when the share is low.  A sparse six-view set reads
+    low, a dense plane source reads ~1; forced either way (A-B flags) and chosen by the counters the gradient is the
+    oracle's; without the counters (an order handed over without them) the general instantiation runs."""
+    R, span = 65, 1.0
+    h = span / (R - 1); ds = h / 2
+    rif_np = cases.luneburg(R)
+    rif = _t(rif_np, gpu)
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = True
+    shares = {}
+    for name, (pos, vel) in (("sparse", cases.cube_rays(2500, span, ds, seed=5, tilt=0.4)),
+                             ("dense", cases.plane_rays(60000, span, ds, seed=6, axis=1, tilt=0.0))):
+        xt, vt = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+        order = drrt_mod.keep_order(drrt_mod.last_order)
+        st = getattr(order, "drrt_march", None)
+        assert st is not None and st.numel() == 2
+        hits, cnt = (int(v) for v in st.cpu())
+        assert 0 <= hits <= cnt and cnt == min(len(pos) // 2, 16384)
+        shares[name] = hits / cnt
+        ones = torch.ones_like(xt)
+        with oracle.arith("factored"):
+            ob = oracle.backtrace(rif_np, rif_np.shape, xt.cpu().numpy(), vt.cpu().numpy(), np.ones_like(pos), np.ones_like(pos),
+                                  h, ds, dtype=np.float32)
+        for mode in ("auto", "ring", "ring_sparse", "ring_general"):
+            with drrt_mod.using(adjoint_window=mode):
+                g = T.backtrace(rif, rif.shape, xt, vt, ones, ones, h, ds, order=order)
+                c = drrt_mod.read_bundle_counters()
+            assert drrt_mod.read_stats()["ray_steps"] == ob["steps_total"], (name, mode)
+            assert cases.rel_l2(g.cpu().numpy(), ob["grad"]) <= 2e-5, (name, mode)
+            if mode == "auto" and c is not None and c["kernel"] != "box":
+                assert c["kernel"] == ("ring_sparse" if shares[name] * 100 < c["sparse_threshold_pct"] else "ring"), (name, c)
+            if mode == "ring_general" and c is not None:
+                assert c["kernel"] in ("box", "ring"), c
+        bare = order.clone()                                  # the order without its counters: never the sparse-only instantiation
+        bare.drrt_steps = order.drrt_steps
+        g = T.backtrace(rif, rif.shape, xt, vt, ones, ones, h, ds, order=bare)
+        c = drrt_mod.read_bundle_counters()
+        assert c is None or c["kernel"] in ("box", "ring")
+        assert cases.rel_l2(g.cpu().numpy(), ob["grad"]) <= 2e-5
+    assert shares["sparse"] < 0.5 < shares["dense"], shares          # 0.6 rays per cell column and view against 14
+
+
 def test_q16_ray_state_mode(gpu, drrt_mod):
     """16-bit ray state "q16" (include/drrt_hip.h): trace_q16io / backtrace_q16io widen exactly, march in fp32 and round
     once -- trace_q16io(enc(x), enc(v)) == enc(trace_f32(dec(enc(x)), dec(enc(v)))) bit for bit, and the adjoint from
