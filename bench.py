@@ -558,6 +558,15 @@ def run_rank(args) -> int:
         for _ in range(warmup):
             step()
         barrier()
+        ms_ar_plain = None
+        if K > 1 and use_dist and args.overlap_reduce:
+            # what ONE whole-grid all-reduce costs in this run (the figure the slab-wise reduce is compared with): timed once,
+            # outside the timed steps, on a scratch copy of the grid
+            scratch = grad.clone()
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier(); e0_.record(); dist.all_reduce(scratch, op=dist.ReduceOp.SUM); e1_.record(); barrier()
+            ms_ar_plain = e0_.elapsed_time(e1_)
+            del scratch
         _lib.check(lib.drrt_profile_begin(8 * steps + 8))
         t0 = time.perf_counter()
         for k in range(steps):
@@ -639,7 +648,7 @@ def run_rank(args) -> int:
                    adj_steps=adj_steps, n_failed=n_failed, ms_fwd=avg("trace"), ms_adj=avg("backtrace"),
                    ms_sort=avg("sort"), ms_zero=avg("zero"), ms_quad=avg("quad"), ms_allreduce=ms_ar, pair=pair,
                    pos=pos, vel=vel, flags=(fflags, aflags, pair), dbg=dbg, adjoint_kernel=choice, chunking=chunking,
-                   overlap=(overlap_info if (K > 1 and use_dist and args.overlap_reduce) else None))
+                   overlap=(overlap_info if (K > 1 and use_dist and args.overlap_reduce) else None), ms_allreduce_plain=ms_ar_plain)
         if keep:                                   # results of the LAST step (the adjoint's grid holds this rank's gradient
             out.update(xt=xt, vt=vt,               # only when there is no all-reduce: parity_check runs at world == 1)
                        grad=grad.clone())
@@ -804,11 +813,12 @@ def run_rank(args) -> int:
             "roofline_fwd": roof_f,
             "phase_ms": {"sort_avg": m["ms_sort"], "zero_grid": m["ms_zero"],
                          "pair_copy": None if m["ms_quad"] != m["ms_quad"] else m["ms_quad"],
-                         "trace": ms_fwd, "backtrace": ms_adj, "allreduce": m["ms_allreduce"] if use_dist else None,
+                         "trace": ms_fwd, "backtrace": ms_adj,
+                         "allreduce": (m["ms_allreduce_plain"] if m.get("ms_allreduce_plain") is not None else m["ms_allreduce"]) if use_dist else None,
                          # one whole-grid reduce after the adjoint: all of it is exposed.  With --adjoint-chunks K
                          # --overlap-reduce (plane-source sets) the planes that are final after each chunk are reduced on a
                          # side stream under the next chunk; `allreduce_exposed` is then what remains after the last chunk and
-                         # `allreduce` the same
+                         # `allreduce` one whole-grid reduce timed once in the same run
                          "allreduce_exposed": m["ms_allreduce"] if use_dist else None,
                          "allreduce_overlapped": bool(m.get("overlap") is not None)},
             "fwd_only_ray_steps_per_s_per_gpu": fwd_steps / (ms_fwd * 1e-3),
