@@ -125,9 +125,10 @@ __device__ __forceinline__ int ring_locate(const Ring& R, int ix, int iy, int iz
 // Flush the k layers g0 .. g0 + k - 1 of axis A (grid coordinates; they must lie inside the live region) into the grid and
 // leave their slots zeroed.  All 64 lanes.  The slots are enumerated x fastest so that the lanes of one atomic instruction
 // cover runs of x-neighbours.
-template <int A>
-__device__ __forceinline__ void ring_flush(win_t* win, const Ring& R, int g0, int k, float* __restrict__ grad, const Vol& V,
-                                           int lane, bool no_global) {
+// WT = double (the general instantiation) or int (the sparse-only one: fixed point, value = slot * qinv).
+template <int A, typename WT>
+__device__ __forceinline__ void ring_flush(WT* win, const Ring& R, int g0, int k, float* __restrict__ grad, const Vol& V,
+                                           int lane, bool no_global, float qinv = 1.0f) {
 #if defined(DRRT_RING_T_NO_FLUSH)
   return;
 #endif
@@ -139,7 +140,7 @@ __device__ __forceinline__ void ring_flush(win_t* win, const Ring& R, int g0, in
   constexpr int kBatch = DRRT_RING_FLUSH_BATCH;
 #pragma unroll 1
   for (int e_base = 0; e_base < total; e_base += kWave * kBatch) {
-    win_t v[kBatch];
+    WT v[kBatch];
     unsigned g[kBatch];
 #pragma unroll
     for (int b = 0; b < kBatch; ++b) {
@@ -154,14 +155,17 @@ __device__ __forceinline__ void ring_flush(win_t* win, const Ring& R, int g0, in
       else        { sy = jy; int rel = jy - R.by; rel = rel < 0 ? rel + R.ny : rel; gy = R.oy + rel; }
       if (A == 2) { const int rel = r0 + jz; sz = R.bz + rel; sz = sz >= R.nz ? sz - R.nz : sz; gz = g0 + jz; }
       else        { sz = jz; int rel = jz - R.bz; rel = rel < 0 ? rel + R.nz : rel; gz = R.oz + rel; }
-      v[b] = (win_t)0;
+      v[b] = (WT)0;
       g[b] = (unsigned)gz * (unsigned)V.sz + (unsigned)gy * (unsigned)V.sy + (unsigned)gx;
       // ds_wrxchg_rtn_b64: read the accumulated value and reset the slot in one LDS op
-      if (e < total) v[b] = __hip_atomic_exchange(win + (sz * R.sz + sy * R.sy + sx), (win_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (e < total) v[b] = __hip_atomic_exchange(win + (sz * R.sz + sy * R.sy + sx), (WT)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
 #pragma unroll
     for (int b = 0; b < kBatch; ++b)
-      if (v[b] != (win_t)0 && !no_global) RING_GADD(grad + g[b], (float)v[b]);
+      if (v[b] != (WT)0 && !no_global) {
+        const float fv = (std::is_same<WT, int>::value) ? (float)v[b] * qinv : (float)v[b];
+        RING_GADD(grad + g[b], fv);
+      }
   }
   wave_lds_fence();
 }
@@ -170,8 +174,8 @@ __device__ __forceinline__ void ring_flush(win_t* win, const Ring& R, int g0, in
 // whose slot is `cur`: the four corners left behind (e0..e3 in (p, q) order) go to the window -- pair / quad DPP
 // pre-reduced as in k_backtrace_flat while PRE -- and (cur, sA) move to the neighbour cell, modulo the window.
 // Returns true when the new cell lies outside the live region on that axis.
-template <bool ABL>
-__device__ __forceinline__ bool ring_cross(win_t* win, int experiment, bool pre, int axis_id, bool fwd, int& cur, int& sA, int sP,
+template <bool ABL, typename WT>
+__device__ __forceinline__ bool ring_cross(WT* win, int experiment, bool pre, int axis_id, bool fwd, int& cur, int& sA, int sP,
                                            int sQ, int nA, int nP, int nQ, int SA, int SP, int SQ, int gA_new, int oA,
                                            float e0, float e1, float e2, float e3, bool& matched,
                                            unsigned& ev_face, unsigned& ev_add, bool dbg) {
@@ -202,13 +206,13 @@ __device__ __forceinline__ bool ring_cross(win_t* win, int experiment, bool pre,
       const bool add = same ? ql == 0u : (psame ? (ql & 1u) == 0u : true);
       if (ABL && dbg) { ++ev_face; ev_add += add; }
       if (add) {
-        win_t* q = win + qi;
+        WT* q = win + qi;
         RING_ADD(q, (same ? s0 : (psame ? q0 : e0)));      RING_ADD(q + dP, (same ? s1 : (psame ? q1 : e1)));
         RING_ADD(q + dQ, (same ? s2 : (psame ? q2 : e2))); RING_ADD(q + dQ + dP, (same ? s3 : (psame ? q3 : e3)));
       }
     } else {
       if (ABL && dbg) { ++ev_face; ++ev_add; }
-      win_t* q = win + qi;
+      WT* q = win + qi;
       RING_ADD(q, e0); RING_ADD(q + dP, e1); RING_ADD(q + dQ, e2); RING_ADD(q + dQ + dP, e3);
     }
   }
@@ -232,19 +236,50 @@ __device__ __forceinline__ bool ring_cross(win_t* win, int experiment, bool pre,
 #define DRRT_RING_SPARSE_WAVES DRRT_RING_WAVES      // (A-B: occupancy of the sparse-only instantiation)
 #endif
 #ifndef DRRT_RING_SPARSE_CAP
-#define DRRT_RING_SPARSE_CAP DRRT_RING_CAP
+#define DRRT_RING_SPARSE_CAP (2 * DRRT_RING_CAP)      // 4-byte slots: the same 10 000 B per wave hold twice the window
 #endif
+// The sparse-only instantiation keeps its window in 32-bit FIXED POINT (slot = round(value * 2^e), one exponent per wave):
+// `ds_add_u32` completes in a third of the time of `ds_add_f64` (tools/lds_random_bench.hip) and, more important, the same
+// LDS holds twice the slots -- the window is twice as long along the rays' travel, slides half as often and fits bundles
+// that a 1250-slot window could not hold (timing-only build with garbage sums, round 4: six rotated views 7.9 -> 6.5 ms,
+// weak medium 5.3 -> 4.5 ms).  What makes it exact enough and safe:
+//   scale     the lane accumulators already carry the factor 2^e (the splat weights are linear in their inputs and a power of
+//             two is an exact factor), chosen so that the largest accumulator of the wave lies in [2^19, 2^20) when the
+//             scale is set -- at the wave's first contributing step, and again whenever the window is EMPTY (a re-fit, a
+//             forced flush) and the largest hand-over since the last such chance has left [2^17, 2^21);
+//   rounding  v_cvt_rpi_i32_f32 (floor(x + 0.5)): half a unit = 2^-20..2^-21 of the wave's largest hand-over, unbiased.  In a
+//             weak medium the gradient is a small difference of large hand-overs, which is what sets the bits needed: with
+//             [2^15, 2^16) the six views through n = 1 + 3e-4 U came out 3.3e-5 from the oracle (bound 2e-5), with
+//             [2^17, 2^18) 9e-6, and one configuration of the differential fuzz 2.1e-5 (round 4);
+//   guard     a hand-over whose largest value is not below 2^23 (or is not finite, or comes before the scale is set)
+//             goes to the grid with fp32 atomics, unscaled, and asks for a re-scale;
+//   overflow  a lane-emit adds less than 2^21 to any slot -- or less than 2^23, and then counts four times -- and after
+//             kQBudget = 1000 counted lane-emits of the wave the whole window is flushed (and zeroed): 1000 * 2^21 < 2^31, no
+//             slot can overflow whatever the rays do.  (Budget 8000 -> 4000 cost 0.03 ms of 7.3 on the six rotated views.)
+#ifndef DRRT_RING_QBITS
+#define DRRT_RING_QBITS 19                   // the wave's largest accumulator is scaled into [2^QBITS, 2^(QBITS+1))
+#endif
+constexpr float kQGuard = (float)(1u << (DRRT_RING_QBITS + 4));   // 2^23: above it a hand-over goes to the grid
+constexpr float kQSmall = (float)(1u << (DRRT_RING_QBITS + 2));   // 2^21: below it a lane-emit counts once against the budget, else four times
+constexpr float kQLow = (float)(1u << (DRRT_RING_QBITS - 2));     // 2^17: the scale is raised when the largest hand-over of a period stays below it
+constexpr unsigned kQBudget = (1u << (31 - (DRRT_RING_QBITS + 2))) - 24u;   // 1000 counted lane-emits between two complete flushes
+__device__ __forceinline__ int cvt_rpi_i32(float f) {          // floor(f + 0.5)
+  int i;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(i) : "v"(f));
+  return i;
+}
 template <bool ABL, bool PAIR, int MODE = 0, bool SPARSE = false>
 __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : DRRT_RING_WAVES) k_backtrace_ring(BackArgs a) {
   constexpr int kRingCap = SPARSE ? DRRT_RING_SPARSE_CAP : DRRT_RING_CAP;
+  using WT = typename std::conditional<SPARSE, int, win_t>::type;
   if (a.select != nullptr) {                                 // launched next to k_backtrace_flat: the bundle
     const bool want_fit = bundles_want_ring(a.select);                                // classification picks one of the three
     if (!want_fit || bundles_want_sparse(a.select, a.order_stats) != SPARSE) return;
   }
-  __shared__ win_t s_win[kAdjWavesPerBlock][kRingCap];
+  __shared__ WT s_win[kAdjWavesPerBlock][kRingCap];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  win_t* win = s_win[wid];
-  for (int k = lane; k < kRingCap; k += kWave) win[k] = (win_t)0;
+  WT* win = s_win[wid];
+  for (int k = lane; k < kRingCap; k += kWave) win[k] = (WT)0;
   wave_lds_fence();
 
   const Vol& V = a.vol;
@@ -334,6 +369,41 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
   // instructions per wave-step, 10.5 -> 8.9 ms; on the metric's dense bundles the same choice costs 6.4 -> 8.8 ms).
   const bool pre = true;
   bool sparse = SPARSE || DRRT_RING_SIMPLE != 0;
+  // fixed-point window (SPARSE): scale of the accumulators and of the window, wave-uniform; see above
+  float qs = 1.0f, qinv = 1.0f;
+  bool qset = false;                                         // the scale has been chosen
+  bool qask = false;                                         // a hand-over left the range: re-scale at the next chance
+  unsigned qbudget = 0u;                                     // lane-emits since the window was last flushed completely
+  float pm_run = 0.f;                                        // per lane: its largest hand-over (scaled) since the scale was set
+  bool qbig = false;                                         // per lane: its last hand-over was of the large class
+  // choose the exponent so that `wm` (the wave's largest accumulator, in the CURRENT scale) maps into [2^19, 2^20)
+  auto q_rescale = [&](float wm) {
+    const int ex = ((__float_as_int(wm) >> 23) & 0xff) - 127;              // floor(log2(wm))
+    int de = DRRT_RING_QBITS - ex;
+    const int e_now = ((__float_as_int(qs) >> 23) & 0xff) - 127;
+    de = max(-100 - e_now, min(100 - e_now, de));
+    const float f = __int_as_float((uni(de) + 127) << 23);                // 2^de, exact
+    p00 = f2{p00.x * f, p00.y * f}; p10 = f2{p10.x * f, p10.y * f}; p01 = f2{p01.x * f, p01.y * f}; p11 = f2{p11.x * f, p11.y * f};
+    qs = __int_as_float((uni(e_now + de) + 127) << 23); qinv = __int_as_float((uni(-(e_now + de)) + 127) << 23);
+    pm_run = 0.f; qset = true; qask = false;
+  };
+  // the wave's largest |accumulator| / hand-over: the order of non-negative floats is the order of their bits
+  // (a lane whose values are not finite does not take part: it goes to the grid on its own and must not keep its wave unscaled)
+  auto q_wave_max = [&](float v) -> float {
+    const float av = fabsf(v);
+    return __int_as_float(wave_max_dpp(__float_as_int(av < 3.0e38f ? av : 0.f)));
+  };
+  auto q_lane_max = [&]() -> float {
+    return fmaxf(fmaxf(fmaxf(fabsf(p00.x), fabsf(p00.y)), fmaxf(fabsf(p10.x), fabsf(p10.y))),
+                 fmaxf(fmaxf(fabsf(p01.x), fabsf(p01.y)), fmaxf(fabsf(p11.x), fabsf(p11.y))));
+  };
+  // a chance to (re-)scale: the window is EMPTY.  Moves the scale only when the wave's largest value of the period since the
+  // last chance has left [2^17, 2^21); the period's maximum starts again either way (magnitudes may also shrink).
+  auto q_adapt = [&]() {
+    const float wm = q_wave_max(fmaxf(pm_run, q_lane_max()));
+    if ((wm > 0.f) & (wm < 3.0e38f) & (!qset | (wm >= kQSmall) | (wm < kQLow) | qask)) q_rescale(wm);
+    pm_run = 0.f; qask = false; qbudget = 0u;
+  };
   unsigned ev_face = 0, ev_add = 0, ev_glob = 0, ev_all8 = 0, ev_wsteps = 0, ev_multi = 0;
   unsigned ev_nofit = 0, ev_service = 0, ev_left = 0, ev_vol = 0, ev_all8g = 0, ev_nopre = 0;   // debug: see the end of the kernel
 
@@ -344,20 +414,37 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
         const int dX = csx == R.nx - 1 ? -(R.nx - 1) : 1;
         const int dY = csy == R.ny - 1 ? -(R.ny - 1) * R.sy : R.sy;
         const int dZ = csz == R.nz - 1 ? -(R.nz - 1) * R.sz : R.sz;
-        win_t* q = win + li;
-        RING_ADD(q, p00.x);             RING_ADD(q + dX, p00.y);
-        RING_ADD(q + dY, p10.x);        RING_ADD(q + dY + dX, p10.y);
-        RING_ADD(q + dZ, p01.x);        RING_ADD(q + dZ + dX, p01.y);
-        RING_ADD(q + dZ + dY, p11.x);   RING_ADD(q + dZ + dY + dX, p11.y);
+        WT* q = win + li;
+        if constexpr (SPARSE) {
+          const float pm = fmaxf(fmaxf(fmaxf(fabsf(p00.x), fabsf(p00.y)), fmaxf(fabsf(p10.x), fabsf(p10.y))),
+                                 fmaxf(fmaxf(fabsf(p01.x), fabsf(p01.y)), fmaxf(fabsf(p11.x), fabsf(p11.y))));
+          if (qset & (pm < kQGuard)) {
+            atomicAdd(q, cvt_rpi_i32(p00.x));             atomicAdd(q + dX, cvt_rpi_i32(p00.y));
+            atomicAdd(q + dY, cvt_rpi_i32(p10.x));        atomicAdd(q + dY + dX, cvt_rpi_i32(p10.y));
+            atomicAdd(q + dZ, cvt_rpi_i32(p01.x));        atomicAdd(q + dZ + dX, cvt_rpi_i32(p01.y));
+            atomicAdd(q + dZ + dY, cvt_rpi_i32(p11.x));   atomicAdd(q + dZ + dY + dX, cvt_rpi_i32(p11.y));
+            pm_run = fmaxf(pm_run, pm);
+            qbig = pm >= kQSmall;
+            return true;
+          }
+          qask = qask | (pm < 3.0e38f);                  // out of range: to the grid, and ask for a re-scale (a hand-over that
+          li = -1;                                       // is not finite goes to the grid as it is and asks for nothing)
+        } else {
+          RING_ADD(q, p00.x);             RING_ADD(q + dX, p00.y);
+          RING_ADD(q + dY, p10.x);        RING_ADD(q + dY + dX, p10.y);
+          RING_ADD(q + dZ, p01.x);        RING_ADD(q + dZ + dX, p01.y);
+          RING_ADD(q + dZ + dY, p11.x);   RING_ADD(q + dZ + dY + dX, p11.y);
+        }
       }
-      return true;
+      if (li >= 0) return true;
     }
     if (experiment != 2) {
       float* g = a.grad + cbase;
-      RING_GADD(g, p00.x);                RING_GADD(g + 1, p00.y);
-      RING_GADD(g + V.sy, p10.x);         RING_GADD(g + V.sy + 1, p10.y);
-      RING_GADD(g + V.sz, p01.x);         RING_GADD(g + V.sz + 1, p01.y);
-      RING_GADD(g + V.sz + V.sy, p11.x);  RING_GADD(g + V.sz + V.sy + 1, p11.y);
+      const float u = SPARSE ? qinv : 1.0f;              // the accumulators of the sparse-only instantiation carry 2^e
+      RING_GADD(g, p00.x * u);                RING_GADD(g + 1, p00.y * u);
+      RING_GADD(g + V.sy, p10.x * u);         RING_GADD(g + V.sy + 1, p10.y * u);
+      RING_GADD(g + V.sz, p01.x * u);         RING_GADD(g + V.sz + 1, p01.y * u);
+      RING_GADD(g + V.sz + V.sy, p11.x * u);  RING_GADD(g + V.sz + V.sy + 1, p11.y * u);
     }
     return false;
   };
@@ -395,6 +482,17 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
         dirty = __ballot(dirty) != 0ull;
       }
     }
+    if constexpr (SPARSE) {                                                   // fixed-point window: scale and budget (wave-uniform)
+      const bool ask = __ballot(qask) != 0ull;
+      if (!qset) {                                                            // the first steps: until something has been accumulated
+        const float wm = q_wave_max(q_lane_max());
+        if ((wm > 0.f) & (wm < 3.0e38f)) q_rescale(wm);
+      } else if ((qbudget >= kQBudget) | ask) {                               // overflow budget used up, or a hand-over left the range
+        if (dirty) { ring_flush<2>(win, R, R.oz, R.nz, a.grad, V, lane, experiment == 2, qinv); dirty = false; ++n_flush; }
+        qask = ask;
+        q_adapt();
+      }
+    }
     // ---- lanes ahead of (or beside) the window: let it follow them (wave-uniform branch) ----
     const unsigned long long mm = __ballot(s.active & miss);
     STAMP(0)                                                                  // top of the iteration, step hint
@@ -419,8 +517,8 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
             else    { k = min((R.nx - 2) - wave_max_dpp(cnt ? rel : -big), R.ox); }
             k = uni(min(k, R.nx));
             if (k > 0) {
-              if (hi) { ring_flush<0>(win, R, R.ox, k, a.grad, V, lane, experiment == 2); R.ox += k; R.bx += k; R.bx = R.bx >= R.nx ? R.bx - R.nx : R.bx; }
-              else    { ring_flush<0>(win, R, R.ox + R.nx - k, k, a.grad, V, lane, experiment == 2); R.ox -= k; R.bx -= k; R.bx = R.bx < 0 ? R.bx + R.nx : R.bx; }
+              if (hi) { ring_flush<0>(win, R, R.ox, k, a.grad, V, lane, experiment == 2, qinv); R.ox += k; R.bx += k; R.bx = R.bx >= R.nx ? R.bx - R.nx : R.bx; }
+              else    { ring_flush<0>(win, R, R.ox + R.nx - k, k, a.grad, V, lane, experiment == 2, qinv); R.ox -= k; R.bx -= k; R.bx = R.bx < 0 ? R.bx + R.nx : R.bx; }
               ++n_slide;
             }
           }
@@ -434,8 +532,8 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
             else    { k = min((R.ny - 2) - wave_max_dpp(cnt ? rel : -big), R.oy); }
             k = uni(min(k, R.ny));
             if (k > 0) {
-              if (hi) { ring_flush<1>(win, R, R.oy, k, a.grad, V, lane, experiment == 2); R.oy += k; R.by += k; R.by = R.by >= R.ny ? R.by - R.ny : R.by; }
-              else    { ring_flush<1>(win, R, R.oy + R.ny - k, k, a.grad, V, lane, experiment == 2); R.oy -= k; R.by -= k; R.by = R.by < 0 ? R.by + R.ny : R.by; }
+              if (hi) { ring_flush<1>(win, R, R.oy, k, a.grad, V, lane, experiment == 2, qinv); R.oy += k; R.by += k; R.by = R.by >= R.ny ? R.by - R.ny : R.by; }
+              else    { ring_flush<1>(win, R, R.oy + R.ny - k, k, a.grad, V, lane, experiment == 2, qinv); R.oy -= k; R.by -= k; R.by = R.by < 0 ? R.by + R.ny : R.by; }
               ++n_slide;
             }
           }
@@ -449,8 +547,8 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
             else    { k = min((R.nz - 2) - wave_max_dpp(cnt ? rel : -big), R.oz); }
             k = uni(min(k, R.nz));
             if (k > 0) {
-              if (hi) { ring_flush<2>(win, R, R.oz, k, a.grad, V, lane, experiment == 2); R.oz += k; R.bz += k; R.bz = R.bz >= R.nz ? R.bz - R.nz : R.bz; }
-              else    { ring_flush<2>(win, R, R.oz + R.nz - k, k, a.grad, V, lane, experiment == 2); R.oz -= k; R.bz -= k; R.bz = R.bz < 0 ? R.bz + R.nz : R.bz; }
+              if (hi) { ring_flush<2>(win, R, R.oz, k, a.grad, V, lane, experiment == 2, qinv); R.oz += k; R.bz += k; R.bz = R.bz >= R.nz ? R.bz - R.nz : R.bz; }
+              else    { ring_flush<2>(win, R, R.oz + R.nz - k, k, a.grad, V, lane, experiment == 2, qinv); R.oz -= k; R.bz -= k; R.bz = R.bz < 0 ? R.bz + R.nz : R.bz; }
               ++n_slide;
             }
           }
@@ -490,7 +588,8 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
             z0 = max(z0, rz - half); z1 = min(z1, rz + half);
             ex = x1 - x0 + 2; ey = y1 - y0 + 2; ez = z1 - z0 + 2;
           }
-          if (dirty) { ring_flush<2>(win, R, R.oz, R.nz, a.grad, V, lane, experiment == 2); dirty = false; ++n_flush; }
+          if (dirty) { ring_flush<2>(win, R, R.oz, R.nz, a.grad, V, lane, experiment == 2, qinv); dirty = false; ++n_flush; }
+          if constexpr (SPARSE) { if (qset) q_adapt(); }     // the window is empty: a chance to re-scale for free
           int nx = ex + DRRT_RING_SLACK_MIN + (int)((float)DRRT_RING_SLACK * fabsf(dx_) * inv_dm + 0.5f);
           int ny = ey + DRRT_RING_SLACK_MIN + (int)((float)DRRT_RING_SLACK * fabsf(dy_) * inv_dm + 0.5f);
           int nz = ez + DRRT_RING_SLACK_MIN + (int)((float)DRRT_RING_SLACK * fabsf(dz_) * inv_dm + 0.5f);
@@ -555,7 +654,9 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
         const float dn = dot3(s.mx, s.my, s.mz, m.gx, m.gy, m.gz);                            // :430
         const float nds = (m.n * a.ds) * a.grad_scale;
         if (regular) {
-          const CornerPairs cp = splat_weights_pk(wx, wy, wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);   // :431-432
+          const float u = SPARSE ? qs : 1.0f;              // (a power of two: an exact factor of every weight)
+          const float ndq = nds * u;
+          const CornerPairs cp = splat_weights_pk(wx, wy, wz, (dn * a.ds) * u, ndq * s.mx, ndq * s.my, ndq * s.mz);   // :431-432
           p00 += cp.c00; p10 += cp.c10; p01 += cp.c01; p11 += cp.c11;
         } else if (experiment != 2 && experiment != 1) {
           const Cell cb = locate(V, px, py, pz);
@@ -613,7 +714,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
                   const float e0 = fwd ? p00.x : p00.y, e1 = fwd ? p10.x : p10.y, e2 = fwd ? p01.x : p01.y, e3 = fwd ? p11.x : p11.y;
                   p00 = fwd ? f2{p00.y, 0.f} : f2{0.f, p00.x}; p10 = fwd ? f2{p10.y, 0.f} : f2{0.f, p10.x};
                   p01 = fwd ? f2{p01.y, 0.f} : f2{0.f, p01.x}; p11 = fwd ? f2{p11.y, 0.f} : f2{0.f, p11.x};
-                  out |= ring_cross<ABL>(win, experiment, pre, 0, fwd, cur, sx, sy, sz, R.nx, R.ny, R.nz, 1, R.sy, R.sz, ix, R.ox,
+                  out |= ring_cross<ABL, WT>(win, experiment, pre, 0, fwd, cur, sx, sy, sz, R.nx, R.ny, R.nz, 1, R.sy, R.sz, ix, R.ox,
                                          e0, e1, e2, e3, matched, ev_face, ev_add, dbg);
                 }
                 if (ddy != 0) {
@@ -622,7 +723,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
                   const f2 ka = fwd ? p10 : p00, kb = fwd ? p11 : p01;
                   p00 = fwd ? ka : f2{0.f, 0.f}; p01 = fwd ? kb : f2{0.f, 0.f};
                   p10 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
-                  out |= ring_cross<ABL>(win, experiment, pre, 1, fwd, cur, sy, sx, sz, R.ny, R.nx, R.nz, R.sy, 1, R.sz, iy, R.oy,
+                  out |= ring_cross<ABL, WT>(win, experiment, pre, 1, fwd, cur, sy, sx, sz, R.ny, R.nx, R.nz, R.sy, 1, R.sz, iy, R.oy,
                                          ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
                 }
                 if (ddz != 0) {
@@ -631,7 +732,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
                   const f2 ka = fwd ? p01 : p00, kb = fwd ? p11 : p10;
                   p00 = fwd ? ka : f2{0.f, 0.f}; p10 = fwd ? kb : f2{0.f, 0.f};
                   p01 = fwd ? f2{0.f, 0.f} : ka; p11 = fwd ? f2{0.f, 0.f} : kb;
-                  out |= ring_cross<ABL>(win, experiment, pre, 2, fwd, cur, sz, sx, sy, R.nz, R.nx, R.ny, R.sz, 1, R.sy, iz, R.oz,
+                  out |= ring_cross<ABL, WT>(win, experiment, pre, 2, fwd, cur, sz, sx, sy, R.nz, R.nx, R.ny, R.sz, 1, R.sy, iz, R.oz,
                                          ea.x, ea.y, eb.x, eb.y, matched, ev_face, ev_add, dbg);
                 }
                 used_lds = true;
@@ -655,7 +756,14 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
       }
     }
     STAMP(4)                                                 // leave: hand-over, new slot
-    dirty = dirty | (__ballot(used_lds) != 0ull);
+    {
+      const unsigned long long ul = __ballot(used_lds);
+      dirty = dirty | (ul != 0ull);
+      if constexpr (SPARSE) {
+        qbudget += (unsigned)__popcll(ul) + 3u * (unsigned)__popcll(__ballot(used_lds & qbig));
+        qbig = false;
+      }
+    }
     if (ABL && dbg) ev_wsteps += lane == 0;
   }
   STAMP(5)
@@ -663,7 +771,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
   // rays still marching when max_steps ran out keep what their cell has accumulated: hand it over
   if (s.active && regular && experiment != 1) { if (emit8(lidx, base, sx, sy, sz)) dirty = true; }
   dirty = __ballot(dirty) != 0ull;
-  if (dirty) { ring_flush<2>(win, R, R.oz, R.nz, a.grad, V, lane, experiment == 2); ++n_flush; }
+  if (dirty) { ring_flush<2>(win, R, R.oz, R.nz, a.grad, V, lane, experiment == 2, qinv); ++n_flush; }
   if (ABL && dbg) {
     if (lane == 0) { atomicAdd(&a.dbg[0], (unsigned long long)n_flush); atomicAdd(&a.dbg[1], (unsigned long long)n_slide);
                      atomicAdd(&a.dbg[2], (unsigned long long)n_fit); atomicAdd(&a.dbg[3], 1ull); }

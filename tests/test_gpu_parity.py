@@ -753,6 +753,7 @@ def test_adjoint_kernel_variants_agree(gpu, oracle, drrt_mod, kind, R, step_res)
     fsteps = getattr(drrt_mod.last_order, "drrt_steps", None)
     assert drrt_mod.last_order is not None and fsteps is not None and fsteps.numel() == n
     variants = [("flat", _lib.FLAG_STATIC_WINDOW), ("auto", 0), ("ring", _lib.FLAG_RING_WINDOW),
+                ("ring_sparse", _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE),
                 ("ring_chord", _lib.FLAG_RING_WINDOW | _lib.FLAG_CHORD_KEY), ("flat_chord", _lib.FLAG_STATIC_WINDOW | _lib.FLAG_CHORD_KEY),
                 ("direct", _lib.FLAG_DIRECT_ATOMICS)]
     for name, fl in variants:
@@ -813,6 +814,8 @@ def test_ring_window_with_rays_that_run_out_of_steps_beside_delayed_lanes(gpu, o
     fsteps = _t(rng.integers(0, 300, n).astype(np.int32), gpu)       # arbitrary "forward iteration counts" -> delays 0..96
     grads = {}
     for name, fl, hint in (("ring+steps", _lib.FLAG_RING_WINDOW, True), ("ring", _lib.FLAG_RING_WINDOW, False),
+                           ("ring_sparse+steps", _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE, True),
+                           ("ring_sparse", _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE, False),
                            ("box", _lib.FLAG_STATIC_WINDOW, False), ("direct", _lib.FLAG_DIRECT_ATOMICS, False)):
         flags = fl | _lib.FLAG_SORT_RAYS
         ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, rif.numel(), flags)) + 1024, dtype=torch.uint8, device=gpu)
@@ -827,7 +830,7 @@ def test_ring_window_with_rays_that_run_out_of_steps_beside_delayed_lanes(gpu, o
         assert int(st[0]) == ob["steps_total"], name
         grads[name] = g.cpu().numpy()
         assert cases.rel_l2(grads[name], ob["grad"]) <= 2e-5, name
-    for name in ("ring+steps", "ring", "box"):
+    for name in ("ring+steps", "ring", "ring_sparse+steps", "ring_sparse", "box"):
         assert cases.rel_l2(grads[name], grads["direct"]) <= 2e-5, name
 
 
@@ -953,6 +956,62 @@ def test_order_pair_stats_pick_the_ring_kernel_instantiation(gpu, oracle, drrt_m
         assert c is None or c["kernel"] in ("box", "ring")
         assert cases.rel_l2(g.cpu().numpy(), ob["grad"]) <= 2e-5
     assert shares["sparse"] < 0.5 < shares["dense"], shares          # 0.6 rays per cell column and view against 14
+
+
+@pytest.mark.parametrize("case", ["wide_range", "growing", "zero_seeds", "one_nan"])
+def test_fixed_point_window_of_the_sparse_ring_kernel(gpu, oracle, drrt_mod, case):
+    """The sparse-only instantiation of k_backtrace_ring keeps its window in 32-bit fixed point with one exponent per wave
+    (csrc/drrt_adjoint_ring.hip): scale chosen at the first contributing step, re-chosen when the window is empty and the
+    magnitudes have drifted, hand-overs out of range sent to the grid, a complete flush before any slot could overflow.
+    Against the oracle (and the general, fp64-window instantiation) with adjoint seeds that stress exactly that:
+      wide_range  seeds spread over 9 decades inside every wave (the small ones lie below the wave's quantum: the GLOBAL
+                  rel-L2 bound holds, and nothing is off by more than a quantum of the largest);
+      growing     a strongly focusing medium and long marches: lambda / mu grow by orders of magnitude along a ray;
+      zero_seeds  nothing to accumulate: the scale is never set, every hand-over is zero;
+      one_nan     one ray with NaN seeds: its own contributions are NaN, every voxel it does not touch is as without it."""
+    R, span = 65, 1.0
+    h = span / (R - 1); ds = h / 2
+    rng = np.random.default_rng(77)
+    rif_np = cases.luneburg(R) if case != "growing" else (1.0 + 1.5 * np.exp(-8.0 * ((np.indices((R, R, R), dtype=np.float32) / (R - 1) - 0.5) ** 2).sum(0))).astype(np.float32)
+    pos, vel = cases.cube_rays(1500, span, ds, seed=9, tilt=0.35)
+    T = drrt_mod.TracerC()
+    drrt_mod.options.sort_rays = True
+    rif = _t(rif_np, gpu)
+    xt, vt = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, ds)
+    order = drrt_mod.keep_order(drrt_mod.last_order)
+    n = xt.shape[0]
+    dx = rng.normal(size=(n, 3)).astype(np.float32); dv = rng.normal(size=(n, 3)).astype(np.float32)
+    if case == "wide_range":
+        sc = (10.0 ** rng.uniform(-6, 3, size=(n, 1))).astype(np.float32)
+        dx *= sc; dv *= sc
+    if case == "zero_seeds":
+        dx[:] = 0; dv[:] = 0
+    if case == "one_nan":
+        dx[n // 2] = np.nan
+    xt_n, vt_n = xt.cpu().numpy(), vt.cpu().numpy()
+    with oracle.arith("factored"):
+        ob = oracle.backtrace(rif_np, rif_np.shape, xt_n, vt_n, dx, dv, h, ds, dtype=np.float32)
+    grads = {}
+    for mode in ("ring_sparse", "ring"):
+        with drrt_mod.using(adjoint_window=mode):
+            grads[mode] = T.backtrace(rif, rif.shape, xt, vt, _t(dx, gpu), _t(dv, gpu), h, ds, order=order).cpu().numpy()
+        assert drrt_mod.read_stats()["ray_steps"] == ob["steps_total"], mode
+    ref = ob["grad"]
+    if case == "zero_seeds":
+        assert not grads["ring_sparse"].any() and not grads["ring"].any()
+        return
+    if case == "one_nan":
+        ok = np.isfinite(ref)
+        assert (~ok).any() and np.array_equal(np.isfinite(grads["ring_sparse"]), ok)
+        with oracle.arith("factored"):            # the same march without that ray: the finite voxels must agree with it
+            keep = np.arange(n) != n // 2
+            ob2 = oracle.backtrace(rif_np, rif_np.shape, xt_n[keep], vt_n[keep], dx[keep], dv[keep], h, ds, dtype=np.float32)
+        assert cases.rel_l2(grads["ring_sparse"][ok], ob2["grad"][ok]) <= 2e-5
+        return
+    for mode in ("ring_sparse", "ring"):
+        assert cases.rel_l2(grads[mode], ref) <= 2e-5, (case, mode, cases.rel_l2(grads[mode], ref))
+    err = np.abs(grads["ring_sparse"].astype(np.float64) - ref)
+    assert err.max() <= 2e-4 * np.abs(ref).max(), (case, err.max(), np.abs(ref).max())
 
 
 def test_q16_ray_state_mode(gpu, drrt_mod):
