@@ -246,23 +246,34 @@ __device__ __forceinline__ bool ring_cross(WT* win, int experiment, bool pre, in
 //   scale     the lane accumulators already carry the factor 2^e (the splat weights are linear in their inputs and a power of
 //             two is an exact factor), chosen so that the largest accumulator of the wave lies in [2^19, 2^20) when the
 //             scale is set -- at the wave's first contributing step, and again whenever the window is EMPTY (a re-fit, a
-//             forced flush) and the largest hand-over since the last such chance has left [2^17, 2^21);
+//             forced flush) and the largest hand-over since the last such chance has left [2^17, 2^20);
 //   rounding  v_cvt_rpi_i32_f32 (floor(x + 0.5)): half a unit = 2^-20..2^-21 of the wave's largest hand-over, unbiased.  In a
 //             weak medium the gradient is a small difference of large hand-overs, which is what sets the bits needed: with
 //             [2^15, 2^16) the six views through n = 1 + 3e-4 U came out 3.3e-5 from the oracle (bound 2e-5), with
-//             [2^17, 2^18) 9e-6, and one configuration of the differential fuzz 2.1e-5 (round 4);
-//   guard     a hand-over whose largest value is not below 2^23 (or is not finite, or comes before the scale is set)
+//             [2^17, 2^18) 9e-6 and one configuration of the differential fuzz 2.1e-5, with [2^19, 2^20) 2.6e-6 (round 4);
+//   guard     a hand-over whose largest value is not below 2^22 (or is not finite, or comes before the scale is set)
 //             goes to the grid with fp32 atomics, unscaled, and asks for a re-scale;
-//   overflow  a lane-emit adds less than 2^21 to any slot -- or less than 2^23, and then counts four times -- and after
-//             kQBudget = 1000 counted lane-emits of the wave the whole window is flushed (and zeroed): 1000 * 2^21 < 2^31, no
-//             slot can overflow whatever the rays do.  (Budget 8000 -> 4000 cost 0.03 ms of 7.3 on the six rotated views.)
+//   overflow  a lane-emit adds less than 2^20 to any slot -- or less than 2^22, and then counts four times -- and after
+//             kQBudget = 2024 counted lane-emits of the wave the whole window is flushed (and zeroed): 2024 * 2^20 < 2^31, no
+//             slot can overflow whatever the rays do.  Six rotated views, same box (gpurun_out/r4p), target range / budget:
+//             [2^17, 2^18) / 4072 -> 7.25-7.43 ms (fuzz fails), [2^18, 2^19) / 2024 -> 7.39-7.43, [2^19, 2^20) / 1000 -> 7.51-7.60,
+//             [2^19, 2^20) with the small class ending at 2^20 / 2024 -> 7.41-7.45 (the default), [2^20, 2^21) / 1000 -> 7.5-7.6.
 #ifndef DRRT_RING_QBITS
 #define DRRT_RING_QBITS 19                   // the wave's largest accumulator is scaled into [2^QBITS, 2^(QBITS+1))
 #endif
-constexpr float kQGuard = (float)(1u << (DRRT_RING_QBITS + 4));   // 2^23: above it a hand-over goes to the grid
-constexpr float kQSmall = (float)(1u << (DRRT_RING_QBITS + 2));   // 2^21: below it a lane-emit counts once against the budget, else four times
-constexpr float kQLow = (float)(1u << (DRRT_RING_QBITS - 2));     // 2^17: the scale is raised when the largest hand-over of a period stays below it
-constexpr unsigned kQBudget = (1u << (31 - (DRRT_RING_QBITS + 2))) - 24u;   // 1000 counted lane-emits between two complete flushes
+#ifndef DRRT_RING_QSMALL
+#define DRRT_RING_QSMALL 1                   // the small class ends 2^QSMALL above the bottom of the target range (at its top)
+#endif
+constexpr float kQSmall = (float)(1u << (DRRT_RING_QBITS + DRRT_RING_QSMALL));       // below it a lane-emit counts once against the budget, else four times
+constexpr float kQGuard = (float)(1u << (DRRT_RING_QBITS + DRRT_RING_QSMALL + 2));   // above it a hand-over goes to the grid
+constexpr float kQLow = (float)(1u << (DRRT_RING_QBITS - 2));     // the scale is raised when the largest hand-over of a period stays below it
+constexpr unsigned kQBudget = (1u << (31 - (DRRT_RING_QBITS + DRRT_RING_QSMALL))) - 24u;   // counted lane-emits between two complete flushes
+// max(|a|, |b|, |c|) in one instruction (the compiler builds fabsf as v_max(|x|, |x|) first: 11 instructions for eight values)
+__device__ __forceinline__ float max3abs(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ int cvt_rpi_i32(float f) {          // floor(f + 0.5)
   int i;
   asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(i) : "v"(f));
@@ -411,13 +422,15 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
   auto emit8 = [&](int li, int cbase, int csx, int csy, int csz) -> bool {
     if (li >= 0) {
       if (experiment != 3) {
+        // (the wrap strides as SCALARS: left to itself the compiler selects the factor per lane and multiplies with the
+        // quarter-rate v_mul_lo_u32)
+        const int wY = uni(-(R.ny - 1) * R.sy), wZ = uni(-(R.nz - 1) * R.sz);
         const int dX = csx == R.nx - 1 ? -(R.nx - 1) : 1;
-        const int dY = csy == R.ny - 1 ? -(R.ny - 1) * R.sy : R.sy;
-        const int dZ = csz == R.nz - 1 ? -(R.nz - 1) * R.sz : R.sz;
+        const int dY = csy == R.ny - 1 ? wY : R.sy;
+        const int dZ = csz == R.nz - 1 ? wZ : R.sz;
         WT* q = win + li;
         if constexpr (SPARSE) {
-          const float pm = fmaxf(fmaxf(fmaxf(fabsf(p00.x), fabsf(p00.y)), fmaxf(fabsf(p10.x), fabsf(p10.y))),
-                                 fmaxf(fmaxf(fabsf(p01.x), fabsf(p01.y)), fmaxf(fabsf(p11.x), fabsf(p11.y))));
+          const float pm = max3abs(max3abs(p00.x, p00.y, p10.x), max3abs(p10.y, p01.x, p01.y), max3abs(p11.x, p11.y, 0.f));
           if (qset & (pm < kQGuard)) {
             atomicAdd(q, cvt_rpi_i32(p00.x));             atomicAdd(q + dX, cvt_rpi_i32(p00.y));
             atomicAdd(q + dY, cvt_rpi_i32(p10.x));        atomicAdd(q + dY + dX, cvt_rpi_i32(p10.y));
