@@ -77,6 +77,11 @@ namespace drrt {
 // brackets around the regions of an iteration, summed over the launch -- where a wave's TIME goes (issue + waiting), which
 // the PMC instruction counts cannot say.  Stamp values go to a buffer of their own that nothing else reads.
 #if defined(DRRT_RING_STAMPS)
+// fixed-point window, per wave: [0] budget used up -> complete flush, [1] a hand-over left the range -> complete flush,
+// [2] budget used up -> the window's largest slot looked at, nothing flushed, [3] re-scales; per lane: [4] hand-overs the
+// guard sent to the grid, [5] hand-overs of the large class
+__device__ unsigned long long g_ring_events[8];
+#define QEVENT(k, n) { if (lane == 0 || (k) >= 4) atomicAdd(&g_ring_events[k], (unsigned long long)(n)); }
 __device__ unsigned long long g_ring_stamps[8];
 #define STAMP_DECL unsigned long long st_t = 0ull, st_acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; unsigned long long st_t0 = __builtin_amdgcn_s_memtime(); st_t = st_t0
 #define STAMP(k) { const unsigned long long st_n = __builtin_amdgcn_s_memtime(); st_acc[k] += st_n - st_t; st_t = st_n; }
@@ -86,6 +91,7 @@ __device__ unsigned long long g_ring_stamps[8];
 #define STAMP_DECL
 #define STAMP(k)
 #define STAMP_END
+#define QEVENT(k, n)
 #endif
 struct Ring {                      // wave-uniform
   int nx, ny, nz;                  // slots per axis (>= 2)
@@ -254,8 +260,18 @@ __device__ __forceinline__ bool ring_cross(WT* win, int experiment, bool pre, in
 //   guard     a hand-over whose largest value is not below 2^22 (or is not finite, or comes before the scale is set)
 //             goes to the grid with fp32 atomics, unscaled, and asks for a re-scale;
 //   overflow  a lane-emit adds less than 2^20 to any slot -- or less than 2^22, and then counts four times -- and after
-//             kQBudget = 2024 counted lane-emits of the wave the whole window is flushed (and zeroed): 2024 * 2^20 < 2^31, no
-//             slot can overflow whatever the rays do.  Six rotated views, same box (gpurun_out/r4p), target range / budget:
+//             kQBudget = 2024 counted lane-emits of the wave the window is LOOKED AT (ten 16-byte LDS reads per lane): while
+//             the scale still fits, the count restarts from what the largest |slot| has really used (the count is a worst
+//             case: every lane-emit on one slot, one sign, top of its class); otherwise -- and whenever a hand-over left
+//             the range -- the whole window is flushed (and zeroed) and the scale re-chosen.  used + counted <= 2024 and
+//             2024 * 2^20 < 2^31: no slot can overflow whatever the rays do.  Events per wave on the six rotated views
+//             (tools/ring_stamps.py, round 4): 8.6 looks that kept the window, 2.0 + 0.2 complete flushes, 3.8 re-scales;
+//             1.5e-4 of the lane hand-overs go to the grid through the guard.  (The looks replaced ~10 complete flushes per
+//             wave and bought nothing measurable: 7.31-7.33 vs 7.32-7.35 ms.  Nor did a second, younger counter that takes
+//             over once the window's rear has passed the place its front had reached -- a moving window renews its slots by
+//             itself -- 7.34-7.44.  A timing-only build without any budget ran 6.95 against 7.25: that is the compiler's
+//             arrangement of the loop without the block, not the flushes.)
+//             Six rotated views, same box (gpurun_out/r4p), target range / budget, complete flushes only:
 //             [2^17, 2^18) / 4072 -> 7.25-7.43 ms (fuzz fails), [2^18, 2^19) / 2024 -> 7.39-7.43, [2^19, 2^20) / 1000 -> 7.51-7.60,
 //             [2^19, 2^20) with the small class ending at 2^20 / 2024 -> 7.41-7.45 (the default), [2^20, 2^21) / 1000 -> 7.5-7.6.
 #ifndef DRRT_RING_QBITS
@@ -397,6 +413,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
     p00 = f2{p00.x * f, p00.y * f}; p10 = f2{p10.x * f, p10.y * f}; p01 = f2{p01.x * f, p01.y * f}; p11 = f2{p11.x * f, p11.y * f};
     qs = __int_as_float((uni(e_now + de) + 127) << 23); qinv = __int_as_float((uni(-(e_now + de)) + 127) << 23);
     pm_run = 0.f; qset = true; qask = false;
+    QEVENT(3, 1)
   };
   // the wave's largest |accumulator| / hand-over: the order of non-negative floats is the order of their bits
   // (a lane whose values are not finite does not take part: it goes to the grid on its own and must not keep its wave unscaled)
@@ -420,6 +437,18 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
 
   // all 8 accumulated corners of the regular cell (window slot li with storage coordinates (csx, csy, csz), or straight to the grid)
   auto emit8 = [&](int li, int cbase, int csx, int csy, int csz) -> bool {
+    // fixed point: the guard decides BEFORE the branch (folded into li: one level of divergent branching less than a test
+    // inside the window path; six rotated views 7.28 / 7.06 -> 7.06 / 7.12 ms on a noisy box, weak medium 4.99 -> 4.93).
+    // A hand-over out of range goes to the grid and asks for a re-scale; one that is not finite goes to the grid as it is
+    // and asks for nothing.
+    float pm = 0.f;
+    if constexpr (SPARSE) {
+      pm = max3abs(max3abs(p00.x, p00.y, p10.x), max3abs(p10.y, p01.x, p01.y), max3abs(p11.x, p11.y, 0.f));
+      const bool okq = qset & (pm < kQGuard);
+      if ((li >= 0) & !okq) { QEVENT(4, 1) }
+      qask = qask | ((li >= 0) & !okq & (pm < 3.0e38f));
+      li = okq ? li : -1;
+    }
     if (li >= 0) {
       if (experiment != 3) {
         // (the wrap strides as SCALARS: left to itself the compiler selects the factor per lane and multiplies with the
@@ -430,18 +459,12 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
         const int dZ = csz == R.nz - 1 ? wZ : R.sz;
         WT* q = win + li;
         if constexpr (SPARSE) {
-          const float pm = max3abs(max3abs(p00.x, p00.y, p10.x), max3abs(p10.y, p01.x, p01.y), max3abs(p11.x, p11.y, 0.f));
-          if (qset & (pm < kQGuard)) {
-            atomicAdd(q, cvt_rpi_i32(p00.x));             atomicAdd(q + dX, cvt_rpi_i32(p00.y));
-            atomicAdd(q + dY, cvt_rpi_i32(p10.x));        atomicAdd(q + dY + dX, cvt_rpi_i32(p10.y));
-            atomicAdd(q + dZ, cvt_rpi_i32(p01.x));        atomicAdd(q + dZ + dX, cvt_rpi_i32(p01.y));
-            atomicAdd(q + dZ + dY, cvt_rpi_i32(p11.x));   atomicAdd(q + dZ + dY + dX, cvt_rpi_i32(p11.y));
-            pm_run = fmaxf(pm_run, pm);
-            qbig = pm >= kQSmall;
-            return true;
-          }
-          qask = qask | (pm < 3.0e38f);                  // out of range: to the grid, and ask for a re-scale (a hand-over that
-          li = -1;                                       // is not finite goes to the grid as it is and asks for nothing)
+          atomicAdd(q, cvt_rpi_i32(p00.x));             atomicAdd(q + dX, cvt_rpi_i32(p00.y));
+          atomicAdd(q + dY, cvt_rpi_i32(p10.x));        atomicAdd(q + dY + dX, cvt_rpi_i32(p10.y));
+          atomicAdd(q + dZ, cvt_rpi_i32(p01.x));        atomicAdd(q + dZ + dX, cvt_rpi_i32(p01.y));
+          atomicAdd(q + dZ + dY, cvt_rpi_i32(p11.x));   atomicAdd(q + dZ + dY + dX, cvt_rpi_i32(p11.y));
+          pm_run = fmaxf(pm_run, pm);
+          qbig = pm >= kQSmall;
         } else {
           RING_ADD(q, p00.x);             RING_ADD(q + dX, p00.y);
           RING_ADD(q + dY, p10.x);        RING_ADD(q + dY + dX, p10.y);
@@ -449,7 +472,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
           RING_ADD(q + dZ + dY, p11.x);   RING_ADD(q + dZ + dY + dX, p11.y);
         }
       }
-      if (li >= 0) return true;
+      return true;
     }
     if (experiment != 2) {
       float* g = a.grad + cbase;
@@ -500,10 +523,31 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
       if (!qset) {                                                            // the first steps: until something has been accumulated
         const float wm = q_wave_max(q_lane_max());
         if ((wm > 0.f) & (wm < 3.0e38f)) q_rescale(wm);
-      } else if ((qbudget >= kQBudget) | ask) {                               // overflow budget used up, or a hand-over left the range
-        if (dirty) { ring_flush<2>(win, R, R.oz, R.nz, a.grad, V, lane, experiment == 2, qinv); dirty = false; ++n_flush; }
-        qask = ask;
-        q_adapt();
+      } else if ((qbudget >= kQBudget) | ask) {                               // overflow budget used up, or a hand-over left the range                           // overflow budget used up, or a hand-over left the range
+        // The budget is a worst case (every counted lane-emit on ONE slot, all of one sign, all at the top of their class).
+        // Before flushing, LOOK: ten 16-byte LDS reads per lane give the window's largest |slot|; while the scale still fits
+        // the period's hand-overs, the budget restarts from what that slot has really used and nothing is flushed.
+        const float wm = q_wave_max(fmaxf(pm_run, q_lane_max()));
+        bool keep = !ask & (wm >= kQLow) & (wm < kQSmall);
+        if (keep) {
+          wave_lds_fence();
+          const int4* w4 = reinterpret_cast<const int4*>(win);
+          int m = 0;
+#pragma unroll 2
+          for (int k = lane; k < kRingCap / 4; k += kWave) {
+            const int4 t = w4[k];
+            m = max(max(m, abs(t.x)), max(max(abs(t.y), abs(t.z)), abs(t.w)));
+          }
+          const unsigned used = ((unsigned)wave_max_dpp(m) >> (DRRT_RING_QBITS + DRRT_RING_QSMALL)) + 1u;
+          keep = used < kQBudget / 2u;
+          if (keep) { qbudget = used; pm_run = 0.f; QEVENT(2, 1) }
+        }
+        if (!keep) {
+          if (dirty) { ring_flush<2>(win, R, R.oz, R.nz, a.grad, V, lane, experiment == 2, qinv); dirty = false; ++n_flush; }
+          if (ask) { QEVENT(1, 1) } else { QEVENT(0, 1) }
+          qask = ask;
+          q_adapt();
+        }
       }
     }
     // ---- lanes ahead of (or beside) the window: let it follow them (wave-uniform branch) ----
@@ -773,6 +817,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
       const unsigned long long ul = __ballot(used_lds);
       dirty = dirty | (ul != 0ull);
       if constexpr (SPARSE) {
+        QEVENT(5, qbig ? 1 : 0)
         qbudget += (unsigned)__popcll(ul) + 3u * (unsigned)__popcll(__ballot(used_lds & qbig));
         qbig = false;
       }
@@ -829,6 +874,14 @@ void launch_backtrace_ring(int mode, bool abl, const BackArgs& a, hipStream_t s)
 }  // namespace drrt
 
 #if defined(DRRT_RING_STAMPS)
+extern "C" __attribute__((visibility("default"))) int drrt_debug_ring_events(unsigned long long* out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(drrt::g_ring_events), sizeof(drrt::g_ring_events)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(drrt::g_ring_events), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
 extern "C" __attribute__((visibility("default"))) int drrt_debug_ring_stamps(unsigned long long* out8, int reset) {
   if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(drrt::g_ring_stamps), sizeof(drrt::g_ring_stamps)) != hipSuccess) return -1;
   if (reset) {

@@ -30,20 +30,30 @@ else:
 T = drrt.TracerC()
 if workload == "metric":
     drrt.options.adjoint_window = "ring"
+fe = getattr(lib, "drrt_debug_ring_events", None)
+if fe is not None:
+    fe.restype, fe.argtypes = C.c_int, [C.c_void_p, C.c_int]
 out = (C.c_ulonglong * 8)()
+ev = (C.c_ulonglong * 8)()
 for rep in range(3):
     xt, vt = T.trace(rif.reshape(-1), (R, R, R), pos, vel, h, ds)
     order = drrt.last_order
     ones = torch.ones_like(xt)
     torch.cuda.synchronize()
     assert fn(None, 1) == 0
+    if fe is not None:
+        fe(None, 1)
     g = T.backtrace(rif.reshape(-1), (R, R, R), xt, vt, ones, ones, h, ds, order=order)
     torch.cuda.synchronize()
     assert fn(out, 0) == 0
+    if fe is not None:
+        fe(ev, 0)
 v = [int(x) for x in out]
 names = ["top + step hint", "window service", "sample + weights (waits for taps)", "step + locate + gather issue + lambda/mu",
          "leave: hand-over + new slot", "epilogue"]
 tot = v[0]
 print(json.dumps({"workload": workload, "waves": v[7], "wave_cycles_total": tot, "cycles_per_wave": tot / max(v[7], 1),
                   "share": {nm: round(v[1 + k] / tot, 4) for k, nm in enumerate(names)},
-                  "adjoint_kernel": drrt.read_bundle_counters()}))
+                  "adjoint_kernel": drrt.read_bundle_counters(),
+                  "fixed_point_events": dict(zip(["forced_flush_budget", "forced_flush_asked", "looked_and_kept", "rescales",
+                                                  "lane_handovers_to_grid_by_guard", "big_class_lane_emits"], [int(x) for x in ev][:6]))}))
