@@ -96,6 +96,8 @@ __device__ unsigned long long g_ring_stamps[8];
 struct Ring {                      // wave-uniform
   int nx, ny, nz;                  // slots per axis (>= 2)
   int sy, sz;                      // LDS strides of y and z in slots: nx, nx * ny
+  int tot;                         // sparse-only instantiation: nx * ny * nz (the wrap strides sy - sz and sz - tot then cost a
+                                   // subtraction each where -(n - 1) * stride costs a quarter-rate v_mul_lo_u32 per hand-over)
   int ox, oy, oz;                  // grid coordinates of the low corner of the live region [o, o + n)
   int bx, by, bz;                  // storage coordinates of that corner: voxel g lives at (b + g - o) mod n
 };
@@ -290,6 +292,11 @@ __device__ __forceinline__ float max3abs(float a, float b, float c) {
   asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+__device__ __forceinline__ float max_raw(float a, float b) {   // one v_max_f32 (fmaxf quiets both operands first: three)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ int cvt_rpi_i32(float f) {          // floor(f + 0.5)
   int i;
   asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(i) : "v"(f));
@@ -327,7 +334,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
   const int experiment = ABL ? a.experiment : 0;
   const bool dbg = ABL && a.dbg != nullptr;
   Ring R;                                                      // the wave's window (wave-uniform); nothing is inside yet
-  R.nx = R.ny = R.nz = 3; R.sy = 3; R.sz = 9; R.ox = R.oy = R.oz = -(1 << 28); R.bx = R.by = R.bz = 0;
+  R.nx = R.ny = R.nz = 3; R.sy = 3; R.sz = 9; R.tot = SPARSE ? 27 : 0; R.ox = R.oy = R.oz = -(1 << 28); R.bx = R.by = R.bz = 0;
   bool fitted = false;
   // the cell the ray stands on (see k_backtrace_flat) + its storage coordinates in the ring
   int base = 0, ix = 0, iy = 0, iz = 0;
@@ -451,9 +458,11 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
     }
     if (li >= 0) {
       if (experiment != 3) {
-        // (the wrap strides as SCALARS: left to itself the compiler selects the factor per lane and multiplies with the
-        // quarter-rate v_mul_lo_u32)
-        const int wY = uni(-(R.ny - 1) * R.sy), wZ = uni(-(R.nz - 1) * R.sz);
+        // the wrap strides -(ny - 1) * sy, -(nz - 1) * sz.  Sparse-only instantiation: two subtractions.  General one (it has
+        // no register for R.tot): as SCALARS -- left to itself the compiler selects the factor per lane and multiplies with
+        // the quarter-rate v_mul_lo_u32
+        const int wY = SPARSE ? R.sy - R.sz : uni(-(R.ny - 1) * R.sy);
+        const int wZ = SPARSE ? R.sz - R.tot : uni(-(R.nz - 1) * R.sz);
         const int dX = csx == R.nx - 1 ? -(R.nx - 1) : 1;
         const int dY = csy == R.ny - 1 ? wY : R.sy;
         const int dZ = csz == R.nz - 1 ? wZ : R.sz;
@@ -463,7 +472,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
           atomicAdd(q + dY, cvt_rpi_i32(p10.x));        atomicAdd(q + dY + dX, cvt_rpi_i32(p10.y));
           atomicAdd(q + dZ, cvt_rpi_i32(p01.x));        atomicAdd(q + dZ + dX, cvt_rpi_i32(p01.y));
           atomicAdd(q + dZ + dY, cvt_rpi_i32(p11.x));   atomicAdd(q + dZ + dY + dX, cvt_rpi_i32(p11.y));
-          pm_run = fmaxf(pm_run, pm);
+          pm_run = max_raw(pm_run, pm);
           qbig = pm >= kQSmall;
         } else {
           RING_ADD(q, p00.x);             RING_ADD(q + dX, p00.y);
@@ -668,7 +677,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
             else if (nx > ex) --nx;
             else break;
           }
-          R.nx = nx; R.ny = ny; R.nz = nz; R.sy = nx; R.sz = nx * ny;
+          R.nx = nx; R.ny = ny; R.nz = nz; R.sy = nx; R.sz = nx * ny; R.tot = SPARSE ? nx * ny * nz : 0;
           // the spare slots lie ahead of the rays
           int ox = dx_ < 0.f ? x0 - (nx - ex) + gh : x0 - gh, oy = dy_ < 0.f ? y0 - (ny - ey) + gh : y0 - gh,
               oz = dz_ < 0.f ? z0 - (nz - ez) + gh : z0 - gh;
