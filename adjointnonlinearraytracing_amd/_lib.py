@@ -97,9 +97,7 @@ SIGNATURES = {
     "drrt_set_step_hint": (None, [_vp, _sz]),
     "drrt_last_bundle_counters": (_vp, []),
     "drrt_ring_threshold_pct": (_i, []),
-    "drrt_ring_sparse_threshold_pct": (_i, []),
-    "drrt_last_order_stats": (_vp, []),
-    "drrt_set_order_stats_hint": (None, [_vp]),
+    "drrt_ring_long_threshold_permille": (_i, []),
     "drrt_profile_begin": (_i, [_i]),
     "drrt_profile_collect": (_i, [_vp, _vp, _i]),
     "drrt_profile_end": (None, []),

@@ -176,8 +176,8 @@ __device__ __forceinline__ bool flat_emit8(win_t* win, int wsy, int wsz, float* 
 }
 
 __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
-  __shared__ unsigned s_cnt[5];                  // the block's five counters: one set of global atomics per block, not per wave
-  if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0u;
+  __shared__ unsigned s_cnt[7];                  // the block's counters ([5] is the host's): one set of global atomics per block, not per wave
+  if (threadIdx.x < 7) s_cnt[threadIdx.x] = 0u;
   __syncthreads();
   const Vol& V = a.vol;
   const size_t t = (size_t)blockIdx.x * kClassifyStride * kBlock + threadIdx.x;
@@ -185,10 +185,12 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
   size_t i;
   bool ok = false;
   int cx = 0, cy = 0, cz = 0, cbase = -1;
+  unsigned fk = 0u;                               // the forward march's iteration count of the ray (step hint), 0 without
   if (ray_index(a.perm, t, a.n, i)) {
     const Ray3 p = ld3(a.xt, i, a.io_half, &a.vol, RAY_POS);
     const Cell c = locate(V, p.x, p.y, p.z);
     cx = c.ix; cy = c.iy; cz = c.iz; cbase = c.base; ok = true;
+    if (a.fsteps != nullptr) fk = a.fsteps[i];
   }
   const int pbase = __builtin_amdgcn_update_dpp(-2, cbase, 0xB1, 0xF, 0xF, false);      // the pair partner's cell (quad_perm [1,0,3,2])
   const unsigned paired = (unsigned)__popcll(__ballot(ok & (pbase == cbase)));
@@ -213,8 +215,12 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
     atomicAdd(&s_cnt[3], lanes);
     if (paired) atomicAdd(&s_cnt[4], paired);
   }
+  // by how many iterations the bundle's rays left the forward march apart
+  const int fki = (int)min(fk, 1u << 30);
+  const int kspread = wave_max_i32(ok ? fki : 0) - wave_min_i32(ok ? fki : big);
+  if (lane == 0 && lanes != 0u && a.fsteps != nullptr && kspread >= kClassifyLongSpread) atomicAdd(&s_cnt[6], 1u);
   __syncthreads();
-  if (threadIdx.x < 5 && s_cnt[threadIdx.x] != 0u) atomicAdd(&a.select[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x < 7 && s_cnt[threadIdx.x] != 0u) atomicAdd(&a.select[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 #ifndef DRRT_ANCHOR_SHIFT

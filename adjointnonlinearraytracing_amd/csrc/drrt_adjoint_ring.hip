@@ -143,7 +143,10 @@ __device__ __forceinline__ void ring_flush(WT* win, const Ring& R, int g0, int k
   wave_lds_fence();
   const int e0 = A == 0 ? k : R.nx, e1 = A == 1 ? k : R.ny, e2 = A == 2 ? k : R.nz;
   const int e01 = e0 * e1, total = e01 * e2;
-  const float inv0 = 1.0f / (float)e0, inv01 = 1.0f / (float)e01;
+  // (v_rcp_f32, not an IEEE division -- ten instructions each, twice per flush: with e < 2500 the quotient (e + 0.5) / e01 keeps
+  // 0.5 / e01 >= 2e-4 from the next integer, the reciprocal's error moves it by < 2500 * 2e-7.  Measured: nothing either way --
+  // nor did 24-bit multiplies for the slot and voxel indices of the flush; the flush waits for LDS and atomics, not for VALU)
+  const float inv0 = __builtin_amdgcn_rcpf((float)e0), inv01 = __builtin_amdgcn_rcpf((float)e01);
   const int r0 = g0 - (A == 0 ? R.ox : (A == 1 ? R.oy : R.oz));       // first layer, relative to the low corner
   constexpr int kBatch = DRRT_RING_FLUSH_BATCH;
 #pragma unroll 1
@@ -234,12 +237,12 @@ __device__ __forceinline__ bool ring_cross(WT* win, int experiment, bool pre, in
 }
 
 // SPARSE: the instantiation without the dense path (no per-axis crossings, no pair-partner sampling): every leave hands over
-//         all eight corners.  Chosen per CALL on the device (bundles_want_sparse: few neighbours of the visit order share
-//         their transverse cell) for ray sets like the reference's six rotated views, where the per-wave rule of the general
-//         instantiation settles on "sparse" for three quarters of the lane-steps anyway -- compiled without the dense
-//         code the same march runs 4-9 % faster (six rotated views 8.49 -> 8.13 ms, the same views through the weak
-//         medium 5.86 -> 5.31 ms, same box, round 4); dense multi-sample views keep the general instantiation (one 45-degree
-//         view at 4 samples per pixel: 7.2 ms against 9.6 ms sparse-only).
+//         all eight corners.  On ray sets like the reference's six rotated views the per-wave rule of the general
+//         instantiation settles on "sparse" for three quarters of the lane-steps anyway; compiled without the dense code the
+//         same march ran 4-9 % faster (six rotated views 8.49 -> 8.13 ms, weak medium 5.86 -> 5.31 ms, round 4) while dense
+//         multi-sample views lost (one 45-degree view at 4 samples per pixel: 7.2 -> 9.6 ms) -- until its window went to
+//         fixed point (below): since then it is the instantiation every call the classification sends to the ring kernel
+//         takes (bundles_want_sparse, drrt_march.h), and the general one serves backtrace_sdf, the counter build and A-B.
 #ifndef DRRT_RING_SPARSE_WAVES
 #define DRRT_RING_SPARSE_WAVES DRRT_RING_WAVES      // (A-B: occupancy of the sparse-only instantiation)
 #endif
@@ -308,7 +311,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
   using WT = typename std::conditional<SPARSE, int, win_t>::type;
   if (a.select != nullptr) {                                 // launched next to k_backtrace_flat: the bundle
     const bool want_fit = bundles_want_ring(a.select);                                // classification picks one of the three
-    if (!want_fit || bundles_want_sparse(a.select, a.order_stats) != SPARSE) return;
+    if (!want_fit || bundles_want_sparse(a.select) != SPARSE) return;
   }
   __shared__ WT s_win[kAdjWavesPerBlock][kRingCap];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;

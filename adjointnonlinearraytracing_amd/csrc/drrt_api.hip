@@ -11,7 +11,7 @@ namespace drrt {
 size_t sort_workspace_bytes(size_t n);
 hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void* pos, const void* vel, int io_half,
                                     float dir_sign, void* ws, size_t ws_bytes, const uint32_t** perm_out,
-                                    hipStream_t stream, bool chord_key, const uint32_t** stats_out);
+                                    hipStream_t stream, bool chord_key);
 }
 
 static thread_local char g_err[512] = "";
@@ -41,14 +41,11 @@ static thread_local const uint32_t* g_last_steps = nullptr;   // per-ray iterati
 static thread_local size_t g_last_steps_n = 0;
 static thread_local const uint32_t* g_hint_steps = nullptr;   // step hint for the NEXT adjoint call
 static thread_local size_t g_hint_steps_n = 0;
-static thread_local const uint32_t* g_last_march = nullptr;   // pair-sharing counters of the last SORTED call's visit order (2 words, device)
-static thread_local const uint32_t* g_hint_march = nullptr;   // ... handed to the NEXT march call together with the order
-struct OrderHint { const uint32_t* order; size_t n; const uint32_t* steps; size_t steps_n; const uint32_t* march; };
+struct OrderHint { const uint32_t* order; size_t n; const uint32_t* steps; size_t steps_n; };
 static inline OrderHint take_hint() {
-  OrderHint h{g_hint_order, g_hint_n, g_hint_steps, g_hint_steps_n, g_hint_march};
+  OrderHint h{g_hint_order, g_hint_n, g_hint_steps, g_hint_steps_n};
   g_hint_order = nullptr; g_hint_n = 0;
   g_hint_steps = nullptr; g_hint_steps_n = 0;
-  g_hint_march = nullptr;
   return h;
 }
 
@@ -57,18 +54,16 @@ extern "C" const uint32_t* drrt_last_order(size_t* n_out) {
   return g_last_order;
 }
 extern "C" void drrt_set_order_hint(const uint32_t* order, size_t n) { g_hint_order = order; g_hint_n = order ? n : 0; }
-extern "C" size_t drrt_order_hint_pending(void) { return g_hint_order ? g_hint_n : (g_hint_steps ? g_hint_steps_n : (g_hint_march ? 1 : 0)); }
+extern "C" size_t drrt_order_hint_pending(void) { return g_hint_order ? g_hint_n : (g_hint_steps ? g_hint_steps_n : 0); }
 extern "C" const uint32_t* drrt_last_steps(size_t* n_out) {
   if (n_out) *n_out = g_last_steps_n;
   return g_last_steps;
 }
 extern "C" void drrt_set_step_hint(const uint32_t* steps, size_t n) { g_hint_steps = steps; g_hint_steps_n = steps ? n : 0; }
-extern "C" const uint32_t* drrt_last_order_stats(void) { return g_last_march; }
-extern "C" void drrt_set_order_stats_hint(const uint32_t* stats2) { g_hint_march = stats2; }
 static thread_local const unsigned* g_last_counters = nullptr;   // bundle classification of the last adjoint call (device, in its workspace)
 extern "C" const unsigned* drrt_last_bundle_counters(void) { return g_last_counters; }
 extern "C" int drrt_ring_threshold_pct(void) { return DRRT_RING_MIN_NOFIT_PCT; }
-extern "C" int drrt_ring_sparse_threshold_pct(void) { return DRRT_RING_SPARSE_MAX_PAIR_PCT; }
+extern "C" int drrt_ring_long_threshold_permille(void) { return DRRT_RING_MIN_LONG_PERMILLE; }
 
 // ---- optional per-kernel timing (bench / profiling aid; not thread-safe) --------------------
 // Event pairs are recorded on the call's stream right around a kernel launch; nothing
@@ -210,9 +205,8 @@ static int zero_stats(drrt_stats* stats, hipStream_t s) {
 
 static int maybe_sort(const Vol& V, float h, size_t n, const void* pos, const void* vel, float dir_sign,
                       unsigned flags, void* ws, size_t ws_bytes, const uint32_t** perm, hipStream_t s,
-                      OrderHint hint, int io_half = 0, const uint32_t** order_stats = nullptr) {
+                      OrderHint hint, int io_half = 0) {
   *perm = nullptr;
-  if (order_stats) *order_stats = (hint.order && hint.n == n) ? hint.march : nullptr;
   // a hint from the caller (normally the paired forward call's order) replaces the sort; it was consumed
   // by this call at its entry (take_hint) whether or not it is usable.  Entries are range-checked on the
   // device (ray_index), so a wrong hint can leave rays unvisited but cannot make a kernel fault.
@@ -220,10 +214,9 @@ static int maybe_sort(const Vol& V, float h, size_t n, const void* pos, const vo
   if (!(flags & DRRT_FLAG_SORT_RAYS) || n < 2) return DRRT_OK;
   if (!ws || ws_bytes < sort_workspace_bytes(n)) return fail(DRRT_ERR_ARG, "workspace too small for DRRT_FLAG_SORT_RAYS");
   ProfScope prof(DRRT_PROF_SORT, s);
-  const uint32_t* st2 = nullptr;
   hipError_t e = sort_rays_by_entry_voxel(V, h, n, pos, vel, io_half, dir_sign, ws, ws_bytes, perm, s,
-                                          (flags & DRRT_FLAG_CHORD_KEY) != 0, &st2);
-  if (e == hipSuccess) { g_last_order = *perm; g_last_order_n = n; g_last_march = st2; if (order_stats) *order_stats = st2; }
+                                          (flags & DRRT_FLAG_CHORD_KEY) != 0);
+  if (e == hipSuccess) { g_last_order = *perm; g_last_order_n = n; }
   return e == hipSuccess ? DRRT_OK : fail_hip(e, "sort_rays_by_entry_voxel");
 }
 
@@ -465,7 +458,7 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
   if (n == 0) return DRRT_OK;
   if (!xt || !vt || !dx || !dv) return fail(DRRT_ERR_ARG, "null ray pointer");
   if (n > 0xffffffffULL) return fail(DRRT_ERR_ARG, "too many rays for uint32 permutation");
-  rc = maybe_sort(a.vol, h, n, xt, vt, -1.f, flags, ws, ws_bytes, &a.perm, s, hint, io_half, &a.order_stats); if (rc) return rc;
+  rc = maybe_sort(a.vol, h, n, xt, vt, -1.f, flags, ws, ws_bytes, &a.perm, s, hint, io_half); if (rc) return rc;
   rc = maybe_pair(a.vol, nvox, n, flags, ws, ws_bytes, s); if (rc) return rc;
   a.io_half = io_half;
   a.sdf = sdf; a.xt = xt; a.vt = vt; a.dx = dx; a.dv = dv; a.grad = grad; a.stats = stats;
@@ -514,11 +507,12 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
         const bool sparse_ok = MODE == 0 && !abl && !(flags & DRRT_FLAG_RING_GENERAL);
         if (!sparse_ok) { e = hipMemsetAsync((char*)a.select + 20, 1, 1, s); if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(select)"); }
         launch_bundle_classify(a, s);
-        if (sparse_ok) launch_backtrace_ring_sparse(a, s);
+        if (sparse_ok) launch_backtrace_ring_sparse(a, s);       // (the classification never picks the general one then)
+        else launch_backtrace_ring(MODE, abl, a, s);
       }
       if (!force_ring) launch_backtrace_box(MODE, abl, a, s);
       if (force_ring && (flags & DRRT_FLAG_RING_SPARSE) && MODE == 0 && !abl) launch_backtrace_ring_sparse(a, s);
-      else if (force_ring || a.select != nullptr) launch_backtrace_ring(MODE, abl, a, s);
+      else if (force_ring) launch_backtrace_ring(MODE, abl, a, s);
     }
   }
   LAUNCH_CHECK("k_backtrace");

@@ -262,7 +262,6 @@ struct BackArgs {
   int experiment;              // development ablations (0 = product behaviour)
   unsigned* select;            // nullable (k_backtrace_flat): [0] waves a fitted window would help, [1] waves classified
   const uint32_t* fsteps;      // nullable: per-ray iteration counts of the forward march that produced (xt, vt) (step hint)
-  const uint32_t* order_stats; // nullable: the visit order's pair-sharing counters (drrt_sort.hip: k_order_pair_stats)
   int xcd_order;               // 1: the launch's blocks take the visit order XCD by XCD (xcd_block)
   // resumable march (drrt_backtrace_chunk_f32; k_backtrace_flat<..., CHUNK = true>): nullable
   float* chunk_state;          // 13 words per visit slot, SoA with stride chunk_stride: x, v, lambda, mu, flags
@@ -327,7 +326,9 @@ __device__ __forceinline__ float quad_sum(float v) {
 //   [0] += 1 when the bounding box of the rays' start cells does not fit the default box window, [1] += 1 per bundle;
 //   [2] += the lanes whose start cell lies more than kClassifyReach cells (on any axis) from the bundle's mean cell,
 //          [3] += the lanes (diagnostic only: it does NOT predict which kernel is faster, see below);
-//   [4] += the lanes whose pair partner (lane ^ 1) starts in the same cell (dense sampling: see bundles_want_sparse).
+//   [4] += the lanes whose pair partner (lane ^ 1) starts in the same cell (diagnostic);
+//   [5]    set by the host: no sparse-only ring instantiation for this call;
+//   [6] += 1 when the bundle's rays left the forward march >= kClassifyLongSpread iterations apart (step hint): see bundles_long.
 // k_backtrace_flat and k_backtrace_ring read the counters (bundles_want_ring): one of them runs.
 // Calibration (tools/probe_classify.py, 256^3, 1M rays unless noted; share of bundles not fitting -> box / ring kernel ms):
 //   metric 4 % -> 4.6 / 6.3; shifted plane 5 % -> 4.7 / 6.4; one view at 0 / 20 / 45 degrees through a weak lens 0 / 13 / 2 %
@@ -341,30 +342,38 @@ constexpr int kClassifyReach = 3;            // 9 slots = 8 cells: the mean cell
 #ifndef DRRT_RING_MIN_NOFIT_PCT
 #define DRRT_RING_MIN_NOFIT_PCT 20
 #endif
-__device__ __forceinline__ bool bundles_want_ring(const unsigned* __restrict__ sel) {
-  return sel[0] * 100u >= sel[1] * (unsigned)DRRT_RING_MIN_NOFIT_PCT && sel[0] != 0u;
-}
-// ... and which instantiation of the ring kernel.  The general one decides wave by wave, every 16 iterations, whether the
-// bundle is dense (at least half of the lanes share their cell with their pair partner: face carry-over + DPP pre-reduction)
-// or sparse (all eight corners handed over on every leave); the sparse-only one is compiled without the dense path and runs
-// the same sparse march 6-9 % faster.  Which of the two a CALL takes is decided from how densely the ray set samples the
-// volume, measured where the lens cannot distort it: in the space the locality sort works in.  ms[0] / ms[1] = the share of
-// pairs of neighbours (2 i, 2 i + 1) of the visit order that travel in the same direction cell through the same
-// grid-cell-sized cell of transverse offset (drrt_sort.hip: k_order_pair_stats; handed over with the order).  The START
-// cells of the adjoint cannot tell (k_bundle_classify's [4]: 0.56 for the six rotated views through the Luneburg ball, 0.49
-// for four dense tomography views -- the first is faster sparse-only, the second general), and sampling the forward march
-// itself cost that kernel 10-15 % (round 4, NOTES.md).  Without the counters, or with sel[5] != 0 (set by the host for
-// backtrace_sdf and the A-B flags), the general instantiation runs.
-#ifndef DRRT_RING_SPARSE_MAX_PAIR_PCT
-#define DRRT_RING_SPARSE_MAX_PAIR_PCT 80     // calibration (round 4, tools/probe_ring_sets.py, 256^3 / 1M rays; share -> general / sparse-only ms):
-                                             //   six rotated views 0.71 -> 8.32 / 7.83 (ball), 5.88 / 5.28 (weak medium); four tomography views
-                                             //   at 4 samples per pixel 0.87 -> 4.98 / 5.62 (blob), 7.32 / 7.11 (ball); one 45-degree view 0.94 ->
-                                             //   7.2 / 9.6; the metric's plane source 1.00
+// Second criterion (round 4, once the sparse-only ring instantiation had its fixed-point window): bundles whose rays left the
+// FORWARD march many iterations apart.  k_backtrace_flat starts every ray at its own exit sample (it ignores the step hint),
+// so such a bundle runs through the volume spread along its path by half a cell per iteration of difference, beyond any 9-slot
+// window, while the start cells (all the first criterion looks at) still fit.  tools/probe_angle_sweep.py +
+// probe_bundle_stats.py (256^3, one plane view of 512^2 x 4 samples at an angle about z; share of bundles whose iteration
+// counts spread over >= 24 -> box / sparse-only ring ms): through the Luneburg ball 0 deg 4.0 % -> 4.46 / 5.06, 1 deg 5.5 % ->
+// 4.96 / 5.16, 2 deg 6.5 % -> 5.01 / 5.43, 5 deg 8.6 % -> 5.77 / 5.15, 10 deg 9.6 % -> 7.46 / 5.42, 20 deg 9.2 % -> 8.06 / 5.42,
+// 30 deg 9.9 % -> 8.66 / 5.75, 45 deg 9.3 % -> 8.10 / 6.00 (shares not fitting: 4, 6, 7, 8, 11, 15, 16, 12 % -- they do not
+// separate the two groups, nor does the mean or any capped mean of the start boxes' extents); through the weak medium, any
+// angle, <= 5 % (the box window wins by 0-20 %); the metric's source 4.2 % -> 4.44 / 5.01, moved by a third of a pixel 5.3 %;
+// six rotated views 27 % (ball), 10 % (weak).  From 7.5 % on the call goes to the ring kernel, whatever the first share says.
+constexpr int kClassifyLongSpread = 24;      // iterations
+#ifndef DRRT_RING_MIN_LONG_PERMILLE
+#define DRRT_RING_MIN_LONG_PERMILLE 75
 #endif
-__device__ __forceinline__ bool bundles_want_sparse(const unsigned* __restrict__ sel, const uint32_t* __restrict__ ms) {
-  return ms != nullptr && sel[5] == 0u && ms[1] != 0u &&
-         (unsigned long long)ms[0] * 100ull < (unsigned long long)ms[1] * (unsigned long long)DRRT_RING_SPARSE_MAX_PAIR_PCT;
+__device__ __forceinline__ bool bundles_long(const unsigned* __restrict__ sel) {
+  return sel[6] * 1000u >= sel[1] * (unsigned)DRRT_RING_MIN_LONG_PERMILLE && sel[6] != 0u;
 }
+__device__ __forceinline__ bool bundles_want_ring(const unsigned* __restrict__ sel) {
+  return (sel[0] * 100u >= sel[1] * (unsigned)DRRT_RING_MIN_NOFIT_PCT && sel[0] != 0u) || bundles_long(sel);
+}
+// ... and which instantiation of the ring kernel: the sparse-only one (compiled without the dense path; 2500-slot fixed-point
+// window) unless sel[5] != 0 -- set by the host for backtrace_sdf, the ablation / counter build and DRRT_FLAG_RING_GENERAL,
+// which only the general instantiation (per-wave dense / sparse rule, fp64 window of 1250 slots) serves.  Until the
+// sparse-only window went to fixed point the choice was made per call from the density of the visit order (pair-sharing
+// counters computed by the sort: the general instantiation was 13-34 % faster on dense 4-samples-per-pixel views); with 2500
+// slots the sparse-only one wins on EVERY set the ring kernel is chosen for (tools/probe_ring_sets.py, round 4, general /
+// sparse-only ms: six rotated views 8.4 / 7.1 (ball), 5.9 / 4.8 (weak medium); four views at 4 samples per pixel 5.0 / 4.3
+// (blob), 7.4 / 6.4 (ball); one view at 45 degrees 7.2 / 6.0, at 20 degrees 6.5 / 5.4), and the counters, their kernel and
+// their hand-over are gone.  (On compact dense sets -- the metric's -- the general instantiation equals the box window,
+// 4.44 ms, and the sparse-only one takes 5.0: those never come here.)
+__device__ __forceinline__ bool bundles_want_sparse(const unsigned* __restrict__ sel) { return sel[5] == 0u; }
 
 // ---------------------------------------------------------------------------------------------
 // cable (radial profile) variants, src/tracer.cpp:312-382 and :511-567

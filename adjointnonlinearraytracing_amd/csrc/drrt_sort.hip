@@ -166,31 +166,6 @@ __global__ void __launch_bounds__(256) k_lightfield_keys(Vol V, size_t n, const 
 
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
-// How densely does the ray set sample the volume?  Neighbours (2 i, 2 i + 1) of the sorted order that share their direction
-// cell and their GRID-CELL-sized cell of transverse offset (the key with the `shift` low bits of its Hilbert index dropped:
-// a key cell is E / 1024 wide over the largest extent E, a grid cell E / (R - 1); 4 bits for a 256^3 grid): stats[0] = such
-// pairs, stats[1] = the pairs looked at (up to 16 384 of them, evenly strided: ONE block, no memset, no global atomics -- a
-// few microseconds on the step).  The adjoint's ring-window kernel picks its instantiation from the ratio (drrt_march.h:
-// bundles_want_sparse).
-__global__ void __launch_bounds__(1024) k_order_pair_stats(const uint32_t* __restrict__ keys, size_t n, uint32_t* __restrict__ stats,
-                                                           int shift) {
-  const size_t npairs = n / 2;
-  const size_t stride = npairs > 16384 ? npairs / 16384 : 1;
-  unsigned hits = 0, cnt = 0;
-#pragma unroll 4
-  for (size_t p = threadIdx.x; p * stride < npairs && p < 16384; p += 1024) {
-    const size_t i = p * stride * 2;
-    hits += ((keys[i] >> shift) == (keys[i + 1] >> shift)) ? 1u : 0u; ++cnt;
-  }
-  __shared__ unsigned s_h, s_c;
-  if (threadIdx.x == 0) { s_h = 0u; s_c = 0u; }
-  __syncthreads();
-  const unsigned wh = wave_sum_u32(hits), wc = wave_sum_u32(cnt);
-  if ((threadIdx.x & 63) == 0 && wc != 0u) { atomicAdd(&s_h, wh); atomicAdd(&s_c, wc); }
-  __syncthreads();
-  if (threadIdx.x == 0) { stats[0] = s_h; stats[1] = s_c; }
-}
-
 // (rocPRIM picks the algorithm by size: up to radix_sort_config<>::merge_sort_limit = 1M items a block sort + merge passes
 // -- 21 launches of 5-9 us for the metric's 1 048 576 rays, 0.167 ms --, Onesweep above.  Lowering the limit so that 1M rays
 // take Onesweep was measured, same box: 0.170 ms at 1M rays, and 0.137 against 0.057 ms for a 131 072-ray shard -- Onesweep's
@@ -217,8 +192,7 @@ size_t sort_workspace_bytes(size_t n) {
 
 hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void* pos, const void* vel, int io_half,
                                     float dir_sign, void* ws, size_t ws_bytes, const uint32_t** perm_out,
-                                    hipStream_t stream, bool chord_key, const uint32_t** stats_out) {
-  if (stats_out) *stats_out = nullptr;
+                                    hipStream_t stream, bool chord_key) {
   (void)h;
   char* base = (char*)ws;
   const size_t k8 = al(n * sizeof(uint64_t)), k4 = al(n * sizeof(uint32_t));
@@ -245,17 +219,6 @@ hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void*
                                   (const uint32_t*)idx_in, idx_out, n, 0u, (unsigned)kLfKeyBits, stream);
   }
   *perm_out = idx_out;
-  if (e == hipSuccess && !chord_key && stats_out != nullptr && n >= 2) {
-    // the pair-sharing counters of this order: two words at the start of the (now free) unsorted-key buffer
-    uint32_t* stats = (uint32_t*)keys_in;
-    // Hilbert-index bits to drop: two per halving of the transverse cell, from the key cell (E / 1024) up to the grid cell
-    const int cells = (V.W > V.H ? (V.W > V.D ? V.W : V.D) : (V.H > V.D ? V.H : V.D)) - 1;
-    int shift = 0;
-    for (int c = cells > 0 ? cells : 1; c < 724 && shift < 2 * kPosBits; c *= 2) shift += 2;      // 724 = 1024 / sqrt(2): round to the nearest level
-    hipLaunchKernelGGL(k_order_pair_stats, dim3(1), dim3(1024), 0, stream, (const uint32_t*)keys_out, n, stats, shift);
-    e = hipGetLastError();
-    *stats_out = stats;
-  }
   return e;
 }
 

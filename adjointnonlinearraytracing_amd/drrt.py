@@ -292,11 +292,6 @@ def _capture_order(n: int, device: torch.device) -> None:
         off_s = int(ptr_s) - ws.data_ptr() if ptr_s else -1
         if ptr_s and cnt.value == n and 0 <= off_s and off_s + 4 * n <= ws.numel():
             last_order.drrt_steps = ws[off_s:off_s + 4 * n].view(torch.int32)
-        # ... and the order's two pair-sharing counters (drrt_last_order_stats): they pick the adjoint's ring-kernel instantiation
-        ptr_m = _lib.load().drrt_last_order_stats()
-        off_m = int(ptr_m) - ws.data_ptr() if ptr_m else -1
-        if ptr_m and 0 <= off_m and off_m + 8 <= ws.numel():
-            last_order.drrt_march = ws[off_m:off_m + 8].view(torch.int32)
 
 
 def keep_order(order: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -309,9 +304,6 @@ def keep_order(order: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     steps = getattr(order, "drrt_steps", None)
     if steps is not None:
         kept.drrt_steps = steps.clone()
-    march = getattr(order, "drrt_march", None)
-    if march is not None:
-        kept.drrt_march = march.clone()
     return kept
 
 
@@ -326,7 +318,6 @@ def _valid_order(order: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 last_bundle_counters: Optional[torch.Tensor] = None
-last_march_stats_used: Optional[torch.Tensor] = None     # the visit order's pair-sharing counters the last adjoint call was handed
 
 
 def _capture_counters(ws: torch.Tensor) -> None:
@@ -344,24 +335,23 @@ def _capture_counters(ws: torch.Tensor) -> None:
 
 def read_bundle_counters() -> Optional[Dict[str, int]]:
     """Synchronising read of `last_bundle_counters` -> which adjoint kernel the last backtrace* call chose, and why.
-    The rule is the library's own (`drrt_ring_threshold_pct()`: its compile-time threshold, so variant builds report
-    what they ran); the counters look at the bundles' START cells, before the step hint's delays."""
+    The rule is the library's own (`drrt_ring_threshold_pct()`, `drrt_ring_long_threshold_permille()`: its compile-time
+    thresholds, so variant builds report what they ran): the ring-window kernel when a fifth of the bundles' START cells do
+    not fit the box window or when 7.5 % of the bundles left the forward march 24 or more iterations apart; its sparse-only
+    instantiation unless the call pinned the general one (counter [5])."""
     if last_bundle_counters is None:
         return None
     c = [int(v) for v in last_bundle_counters.cpu()]
     share = c[0] / c[1] if c[1] else 0.0
     pct = int(_lib.load().drrt_ring_threshold_pct())
-    ring = bool(c[0] and c[0] * 100 >= c[1] * pct)
-    m = last_march_stats_used
-    mshare = None
-    if m is not None:
-        mm = [int(v) for v in m.cpu()]
-        mshare = (mm[0] / mm[1]) if mm[1] else None
-    spct = int(_lib.load().drrt_ring_sparse_threshold_pct())
-    sparse = ring and c[5] == 0 and mshare is not None and mshare * 100 < spct
+    ext = int(_lib.load().drrt_ring_long_threshold_permille())
+    long_ = bool(c[6] and c[6] * 1000 >= c[1] * ext)
+    ring = bool(c[0] and c[0] * 100 >= c[1] * pct) or long_
+    sparse = ring and c[5] == 0
     return dict(bundles_not_fitting=c[0], bundles=c[1], lanes_outside=c[2], lanes=c[3], not_fitting_share=share,
-                start_pair_share=(c[4] / c[3] if c[3] else 0.0), order_pair_share=mshare,
-                ring_threshold_pct=pct, sparse_threshold_pct=spct,
+                start_pair_share=(c[4] / c[3] if c[3] else 0.0),
+                bundles_long=c[6], long_bundle_share=(c[6] / c[1] if c[1] else 0.0), long_threshold_permille=ext,
+                ring_threshold_pct=pct,
                 kernel=("ring_sparse" if sparse else "ring") if ring else "box")
 
 
@@ -388,9 +378,6 @@ def _hint(order: Optional[torch.Tensor], n: int) -> bool:
         steps = getattr(order, "drrt_steps", None)
         if steps is not None and steps.numel() == n and steps.dtype == torch.int32 and steps.device == order.device:
             _lib.load().drrt_set_step_hint(C.c_void_p(steps.data_ptr()), n)
-        march = getattr(order, "drrt_march", None)
-        if march is not None and march.numel() == 2 and march.dtype == torch.int32 and march.device == order.device:
-            _lib.load().drrt_set_order_stats_hint(C.c_void_p(march.data_ptr()))
         return True
     return False
 
@@ -400,7 +387,6 @@ def _clear_hint() -> None:
     is never reached (an exception while marshalling arguments)."""
     _lib.load().drrt_set_order_hint(None, 0)
     _lib.load().drrt_set_step_hint(None, 0)
-    _lib.load().drrt_set_order_stats_hint(None)
 
 
 # "failed to exit all rays" (src/tracer.cpp:90) without a host sync per call: the stats block is copied to pinned
@@ -592,19 +578,12 @@ class TracerC:
             (fl, ws), st = _march_workspace(rif_, res, n, h, ds, fl, dev, paired=order is not None, adjoint=True), _new_stats(dev)
             fn = _lib.load().drrt_backtrace_q16io if q16 else (_lib.load().drrt_backtrace_f16io if half else _lib.load().drrt_backtrace_f32)
             try:
-                global last_march_stats_used
-                last_march_stats_used = getattr(order, "drrt_march", None) if order is not None else None
                 if not _hint(order, n):
                     _bump_order_gen(dev)               # the adjoint sorts for itself: it rewrites the order region
                 _lib.check(fn(
                     _p(rif_), rif_.numel(), _res3(res), n, _p(xt_), _p(vt_), _p(dx_), _p(dv_),
                     float(h), float(ds), _p(grad), _p(st), _p(ws), ws.numel(), fl, _stream(dev)))
                 _capture_counters(ws)
-                if order is None:                      # the adjoint sorted for itself: it used its own order's counters
-                    pm = _lib.load().drrt_last_order_stats()
-                    om = int(pm) - ws.data_ptr() if pm else -1
-                    if pm and (fl & _lib.FLAG_SORT_RAYS) and 0 <= om and om + 8 <= ws.numel():
-                        last_march_stats_used = ws[om:om + 8].view(torch.int32).clone()
             finally:
                 _clear_hint()
         return grad

@@ -490,7 +490,6 @@ def run_rank(args) -> int:
         torch.cuda.synchronize(dev)
 
     ring_pct = int(lib.drrt_ring_threshold_pct())
-    sparse_pct = int(lib.drrt_ring_sparse_threshold_pct())
 
     def bench_rays(pos, vel, steps, warmup, force_flags=None, keep=False, rif=rif, robust=False):
         """Time `steps` fwd + adjoint passes over the rays (pos, vel) resident on the device; -> this rank's measurements.
@@ -516,7 +515,6 @@ def run_rank(args) -> int:
                                           p(st_f), p(ws), ws.numel(), fflags, stream))
             if (flags & _lib.FLAG_SORT_RAYS) and not args.no_order_reuse:    # adjoint visits rays in the forward's bundle order
                 lib.drrt_set_order_hint(lib.drrt_last_order(None), n)
-                lib.drrt_set_order_stats_hint(lib.drrt_last_order_stats())   # (the order's density counters: ring-kernel instantiation)
                 if not args.no_step_hint:                                    # ... on the forward march's clock
                     lib.drrt_set_step_hint(lib.drrt_last_steps(None), n)
             overlap = K > 1 and use_dist and args.overlap_reduce
@@ -598,19 +596,14 @@ def run_rank(args) -> int:
             off = int(cptr) - ws.data_ptr()
             if 0 <= off and off + 32 <= ws.numel():
                 c = ws[off:off + 32].view(torch.int32).cpu().tolist()
-                ring = bool(c[0] and c[0] * 100 >= c[1] * ring_pct)
-                mshare = None
-                mptr = lib.drrt_last_order_stats()
-                if mptr:
-                    moff = int(mptr) - ws.data_ptr()
-                    if 0 <= moff and moff + 8 <= ws.numel():
-                        mm = ws[moff:moff + 8].view(torch.int32).cpu().tolist()
-                        mshare = (mm[0] / mm[1]) if mm[1] else None
-                sparse = ring and c[5] == 0 and mshare is not None and mshare * 100 < sparse_pct
+                ext_min = int(lib.drrt_ring_long_threshold_permille())
+                long_ = bool(c[6] and c[6] * 1000 >= c[1] * ext_min)
+                ring = bool(c[0] and c[0] * 100 >= c[1] * ring_pct) or long_
+                sparse = ring and c[5] == 0
                 choice = {"kernel": ("ring_sparse" if sparse else "ring") if ring else "box",
                           "bundles_not_fitting": c[0], "bundles_sampled": c[1], "ring_threshold_pct": ring_pct,
                           "lanes_far_from_bundle": c[2], "lanes_sampled": c[3],
-                          "order_pair_share": mshare, "sparse_max_pair_pct": sparse_pct}
+                          "long_bundle_share": round(c[6] / c[1], 4) if c[1] else None, "ring_min_long_permille": ext_min}
         t = torch.tensor([elapsed, float(fwd_steps), float(adj_steps)], dtype=torch.float64, device=dev)
         if use_dist:
             tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

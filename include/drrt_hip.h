@@ -170,16 +170,6 @@ DRRT_API size_t drrt_order_hint_pending(void);
 DRRT_API const uint32_t* drrt_last_steps(size_t* n_out);
 DRRT_API void drrt_set_step_hint(const uint32_t* steps, size_t n);
 
-/* How densely does the ray set sample the volume?  Every call that sorts its rays (light-field key) leaves two uint32
- * counters next to the order (DEVICE pointer into that call's workspace; NULL when the last sorted call left none): [0] the
- * pairs of neighbours (2 i, 2 i + 1) of the visit order that travel in the same direction cell through the same
- * grid-cell-sized cell of transverse offset, [1] all pairs.  They belong to the ORDER: hand them over with it (same rules as
- * the other hints: per thread, consumed by the next march call, speed only; ignored without a matching order hint).  The
- * adjoint's ring-window kernel picks its instantiation from them: below drrt_ring_sparse_threshold_pct() % the sparse-only
- * one.  Without them the general instantiation runs; an adjoint that sorts for itself uses its own. */
-DRRT_API const uint32_t* drrt_last_order_stats(void);
-DRRT_API void drrt_set_order_stats_hint(const uint32_t* stats2);
-
 /* Which adjoint kernel ran, and why: a DEVICE pointer to the four counters of the bundle classification of the last
  * drrt_backtrace_* / drrt_backtrace_sdf_f32 call on this host thread that classified its bundles (it lies in that call's
  * workspace: valid while the workspace is, read it after synchronising the stream), or NULL when that call did not (no visit
@@ -187,14 +177,17 @@ DRRT_API void drrt_set_order_stats_hint(const uint32_t* stats2);
  *   [0] bundles whose start cells do not fit the box window, [1] bundles looked at,
  *   [2] lanes whose start cell lies more than 3 cells from their bundle's mean cell, [3] lanes looked at (diagnostic),
  *   [4] lanes whose pair partner (lane ^ 1) starts in the same cell (diagnostic), [5] non-zero when the call pinned the
- *   general instantiation of the ring kernel (8 ints in all; [6], [7] unused).  Which instantiation of the ring kernel runs
- *   is decided from the visit order's pair-sharing counters (drrt_last_order_stats), not from these.
+ *   general instantiation of the ring kernel, [6] bundles whose rays' forward iteration counts (step hint) spread over 24 or
+ *   more (0 without a hint) (8 ints in all; [7] unused).
  * The ring-window kernel runs when [0] * 100 >= [1] * drrt_ring_threshold_pct() (the library's compile-time threshold, 20 in
- * the product build; calibration: csrc/drrt_march.h, bundles_want_ring).  The counters describe the START cells of the
+ * the product build) or when [6] * 1000 >= [1] * drrt_ring_long_threshold_permille() (75: the box-window kernel does not use
+ * the step hint, so rays that left the forward march that far apart run spread along their path beyond its window); its
+ * sparse-only instantiation (fixed-point window) unless [5] is set.  Calibration:
+ * csrc/drrt_march.h, bundles_want_ring / bundles_long / bundles_want_sparse.  The counters describe the START cells of the
  * bundles (the exit rays as given), not where the step hint's delays put the lanes later on. */
 DRRT_API const unsigned* drrt_last_bundle_counters(void);
 DRRT_API int drrt_ring_threshold_pct(void);
-DRRT_API int drrt_ring_sparse_threshold_pct(void);      /* sparse-only ring instantiation when order stats [0] * 100 < [1] * this */
+DRRT_API int drrt_ring_long_threshold_permille(void);   /* ring kernel also when counters [6] * 1000 >= [1] * this */
 
 /* ---- 16-bit ray state "q16" (BASELINE.json config 5: "fp16 ray state + fp32 adjoint accumulate") -----------------
  * The reference is fp32-only (include/types.h:36-46).  IEEE half keeps 11 significant bits wherever the value is:

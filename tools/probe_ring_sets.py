@@ -61,7 +61,7 @@ def probe(name, n, xs, vs, force=None):
         out[mode + "_ms"] = round(ta, 3)
         if c is not None:
             out[mode + "_kernel"] = c["kernel"]
-            out["not_fitting_share"], out["pair_share"] = round(c["not_fitting_share"], 3), round(c["order_pair_share"] or -1, 3)
+            out["not_fitting_share"], out["long_share"] = round(c["not_fitting_share"], 3), round(c["long_bundle_share"], 3)
     out["adj_ray_steps"] = drrt.read_stats()["ray_steps"]
     print(json.dumps(out), flush=True)
 
