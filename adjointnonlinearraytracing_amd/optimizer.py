@@ -95,72 +95,99 @@ class MaskedAdam(optim.Optimizer):
         return loss
 
 
+_ADAM_HYPER = ("betas", "lr", "weight_decay", "eps")
+_MASKED_HYPER = ("mask_boundary", "clamp_min")
+
+
+def _stepped_moments(optimizer: optim.Optimizer):
+    """-> (hyper-parameter group, Adam state) of the last parameter of ``optimizer`` that has taken a step, or
+    (last group, None) when none has."""
+    hyper, moments = None, None
+    for hyper in optimizer.param_groups:
+        for p in hyper["params"]:
+            st = optimizer.state[p]
+            if len(st):
+                moments = st
+    return hyper, moments
+
+
 def reload_opto(old_o: optim.Optimizer, n: torch.Tensor, lr: float) -> optim.Optimizer:
-    """core/optimizer.py:13-41: new Adam for the up-sampled parameter ``n`` whose moments are the
-    up-sampled moments of the previous level (hyper-parameters carried over).  A ``MaskedAdam`` yields a ``MaskedAdam``."""
-    ogroup, state = None, None
-    for group in old_o.param_groups:
-        ogroup = group
-        for p in group["params"]:
-            if len(old_o.state[p]) == 0:
-                continue
-            ostate = old_o.state[p]
-            state = dict(step=ostate["step"],
-                         exp_avg=upres_scene(ostate["exp_avg"], n.shape[0]),
-                         exp_avg_sq=upres_scene(ostate["exp_avg_sq"], n.shape[0]))
-    fused = isinstance(old_o, MaskedAdam)
-    opto = MaskedAdam([n], lr=lr) if fused else optim.Adam([n], lr=lr)
-    for group in opto.param_groups:
-        if ogroup is not None:
-            for key in ("betas", "lr", "weight_decay", "eps") + (("mask_boundary", "clamp_min") if fused else ()):
-                group[key] = ogroup[key]
-        for p in group["params"]:
-            if state is not None:
-                opto.state[p] = state
-    return opto
+    """Same contract as core/optimizer.py:13-41: an Adam for the up-sampled parameter ``n`` that continues the previous
+    level's run -- its step count, its first and second moments trilinearly up-sampled to ``n``'s resolution
+    (``upres_scene``), its hyper-parameters (``lr`` included: like the reference's, the ``lr`` argument only seeds the
+    constructor).  A ``MaskedAdam`` yields a ``MaskedAdam`` (+ its two extra hyper-parameters)."""
+    masked = isinstance(old_o, MaskedAdam)
+    hyper, moments = _stepped_moments(old_o)
+    fresh = (MaskedAdam if masked else optim.Adam)([n], lr=lr)
+    carried = None
+    if moments is not None:
+        side = n.shape[0]
+        carried = {"step": moments["step"],
+                   "exp_avg": upres_scene(moments["exp_avg"], side),
+                   "exp_avg_sq": upres_scene(moments["exp_avg_sq"], side)}
+    for group in fresh.param_groups:
+        if hyper is not None:
+            group.update({k: hyper[k] for k in _ADAM_HYPER + (_MASKED_HYPER if masked else ())})
+        if carried is not None:
+            for p in group["params"]:
+                fresh.state[p] = carried
+    return fresh
+
+
+def _boundary_mask(n: torch.Tensor) -> torch.Tensor:
+    """True on the outermost voxel layer (core/optimizer.py:54-55)."""
+    shell = torch.ones_like(n, dtype=torch.bool)
+    shell[1:-1, 1:-1, 1:-1] = False
+    return shell
+
+
+def _run_level(func, n, opto, steps, first_iteration, log_func, fused):
+    """``steps`` optimisation steps on one resolution level -> the level's losses (device scalars).  ``fused``: mask +
+    Adam + clamp are MaskedAdam's one HIP pass; otherwise the reference's three statements (:61, :63, :66)."""
+    shell = None if fused else _boundary_mask(n)
+    losses = []
+    for k in range(steps):
+        opto.zero_grad()
+        loss = func(n)
+        loss.backward()
+        with torch.no_grad():
+            if log_func is not None:
+                log_func(first_iteration + k, n)                                            # :60
+            if shell is not None:
+                n.grad[shell] = 0
+        opto.step()
+        with torch.no_grad():
+            if shell is not None:
+                n.clamp_(min=1)
+            losses.append(loss.detach().reshape(()))
+    return losses
 
 
 def multires_opt(func, eta, iterations, res_list, log_func=None, lr=1e-3, statename="result", fused=True):
-    """core/optimizer.py:44-84: coarse-to-fine Adam optimisation of the volume ``eta`` -- ``iterations * (level + 1)``
-    steps per entry of ``res_list``, boundary gradients masked, values clamped at 1, the volume and the Adam moments
-    up-sampled between levels, a checkpoint saved per level.  Returns ``(n, loss_hist)`` like the reference.
+    """Same contract as core/optimizer.py:44-84: coarse-to-fine Adam optimisation of the volume ``eta`` --
+    ``iterations * (level + 1)`` steps on level ``level`` of ``res_list``, boundary gradients masked, values clamped at 1,
+    a checkpoint ``statename`` (keys ``rif``, ``opto_state_dict``, ``loss_hist``) after every level, then the volume and the
+    Adam moments up-sampled to the next entry of ``res_list`` with the learning-rate seed halved per level.  Returns
+    ``(n, loss_hist)``.
 
     ``fused=True`` (default) runs mask + Adam + clamp as one HIP pass (``MaskedAdam``); ``fused=False`` runs the
     reference's statements literally (A/B and parity testing).  Differences from the reference as written: ``log_func``
-    may be None; no tqdm bars; the loss history is collected on the device and read back once per level instead of
-    ``loss.item()`` every iteration (a host sync per step)."""
-    n = eta.clone()
-    n.requires_grad = True
+    may be None; no tqdm bars; the losses stay on the device and are read back once per level instead of ``loss.item()``
+    every iteration (a host sync per step)."""
+    n = eta.clone().requires_grad_(True)
     opto = MaskedAdam([n], lr=lr) if fused else optim.Adam([n], lr=lr)
-    iteration_count = 0
-    loss_hist = []
-    for res_iter in range(len(res_list)):
-        if not fused:
-            mask = torch.ones_like(n, dtype=torch.bool, requires_grad=False)               # :54-55
-            mask[1:-1, 1:-1, 1:-1] = 0
-        level_losses = []
-        for _ in range(iterations * (res_iter + 1)):                                        # :56
-            opto.zero_grad()
-            loss = func(n)
-            loss.backward()
-            with torch.no_grad():
-                if log_func is not None:
-                    log_func(iteration_count, n)                                            # :60
-                if not fused:
-                    n.grad[mask] = 0                                                        # :61
-            opto.step()                                                                     # :63 (fused: + :61, :66)
-            with torch.no_grad():
-                if not fused:
-                    n.clamp_(min=1)                                                         # :66
-                level_losses.append(loss.detach())
-            iteration_count += 1
+    done, loss_hist = 0, []
+    levels = len(res_list)
+    for level in range(levels):
+        steps = iterations * (level + 1)                                                    # :56
+        losses = _run_level(func, n, opto, steps, done, log_func, fused)
+        done += steps
         with torch.no_grad():
-            if level_losses:
-                loss_hist.extend(torch.stack([l.reshape(()) for l in level_losses]).cpu().tolist())   # :67
+            if losses:
+                loss_hist += torch.stack(losses).cpu().tolist()                             # :67, one read-back per level
             torch.save({"rif": n, "opto_state_dict": opto.state_dict(), "loss_hist": torch.tensor(loss_hist)},
                        statename)                                                           # :72-76
-            if res_iter < len(res_list) - 1:
-                n = upres_scene(n, res_list[res_iter + 1])                                  # :78
-                n.requires_grad = True
-                opto = reload_opto(opto, n, (0.5 ** res_iter) * lr)                         # :80
+            if level + 1 < levels:
+                n = upres_scene(n, res_list[level + 1]).requires_grad_(True)                # :78
+                opto = reload_opto(opto, n, lr * 0.5 ** level)                              # :80
     return n, loss_hist
