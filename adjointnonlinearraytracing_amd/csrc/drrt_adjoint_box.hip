@@ -215,10 +215,11 @@ __global__ void __launch_bounds__(kBlock) k_bundle_classify(BackArgs a) {
     atomicAdd(&s_cnt[3], lanes);
     if (paired) atomicAdd(&s_cnt[4], paired);
   }
-  // by how many iterations the bundle's rays left the forward march apart
+  // by how many iterations the bundle's rays left the forward march apart -- as a length: iterations * ds, in cells
   const int fki = (int)min(fk, 1u << 30);
   const int kspread = wave_max_i32(ok ? fki : 0) - wave_min_i32(ok ? fki : big);
-  if (lane == 0 && lanes != 0u && a.fsteps != nullptr && kspread >= kClassifyLongSpread) atomicAdd(&s_cnt[6], 1u);
+  const bool long_ = (float)kspread * a.ds * V.inv_h >= kClassifyLongCells;
+  if (lane == 0 && lanes != 0u && a.fsteps != nullptr && long_) atomicAdd(&s_cnt[6], 1u);
   __syncthreads();
   if (threadIdx.x < 7 && s_cnt[threadIdx.x] != 0u) atomicAdd(&a.select[threadIdx.x], s_cnt[threadIdx.x]);
 }

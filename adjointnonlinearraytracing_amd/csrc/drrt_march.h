@@ -328,7 +328,8 @@ __device__ __forceinline__ float quad_sum(float v) {
 //          [3] += the lanes (diagnostic only: it does NOT predict which kernel is faster, see below);
 //   [4] += the lanes whose pair partner (lane ^ 1) starts in the same cell (diagnostic);
 //   [5]    set by the host: no sparse-only ring instantiation for this call;
-//   [6] += 1 when the bundle's rays left the forward march >= kClassifyLongSpread iterations apart (step hint): see bundles_long.
+//   [6] += 1 when the bundle's rays left the forward march >= kClassifyLongCells / (ds / h) iterations apart (step hint):
+//          see bundles_long.
 // k_backtrace_flat and k_backtrace_ring read the counters (bundles_want_ring): one of them runs.
 // Calibration (tools/probe_classify.py, 256^3, 1M rays unless noted; share of bundles not fitting -> box / ring kernel ms):
 //   metric 4 % -> 4.6 / 6.3; shifted plane 5 % -> 4.7 / 6.4; one view at 0 / 20 / 45 degrees through a weak lens 0 / 13 / 2 %
@@ -346,14 +347,14 @@ constexpr int kClassifyReach = 3;            // 9 slots = 8 cells: the mean cell
 // FORWARD march many iterations apart.  k_backtrace_flat starts every ray at its own exit sample (it ignores the step hint),
 // so such a bundle runs through the volume spread along its path by half a cell per iteration of difference, beyond any 9-slot
 // window, while the start cells (all the first criterion looks at) still fit.  tools/probe_angle_sweep.py +
-// probe_bundle_stats.py (256^3, one plane view of 512^2 x 4 samples at an angle about z; share of bundles whose iteration
-// counts spread over >= 24 -> box / sparse-only ring ms): through the Luneburg ball 0 deg 4.0 % -> 4.46 / 5.06, 1 deg 5.5 % ->
+// probe_bundle_stats.py (256^3, ds = h / 2, one plane view of 512^2 x 4 samples at an angle about z; share of bundles whose
+// iteration counts spread over >= 24 = 12 cells of travel -> box / sparse-only ring ms): through the Luneburg ball 0 deg 4.0 % -> 4.46 / 5.06, 1 deg 5.5 % ->
 // 4.96 / 5.16, 2 deg 6.5 % -> 5.01 / 5.43, 5 deg 8.6 % -> 5.77 / 5.15, 10 deg 9.6 % -> 7.46 / 5.42, 20 deg 9.2 % -> 8.06 / 5.42,
 // 30 deg 9.9 % -> 8.66 / 5.75, 45 deg 9.3 % -> 8.10 / 6.00 (shares not fitting: 4, 6, 7, 8, 11, 15, 16, 12 % -- they do not
 // separate the two groups, nor does the mean or any capped mean of the start boxes' extents); through the weak medium, any
 // angle, <= 5 % (the box window wins by 0-20 %); the metric's source 4.2 % -> 4.44 / 5.01, moved by a third of a pixel 5.3 %;
 // six rotated views 27 % (ball), 10 % (weak).  From 7.5 % on the call goes to the ring kernel, whatever the first share says.
-constexpr int kClassifyLongSpread = 24;      // iterations
+constexpr float kClassifyLongCells = 12.f;   // iterations * ds / h (24 iterations at the calibration's ds = h / 2)
 #ifndef DRRT_RING_MIN_LONG_PERMILLE
 #define DRRT_RING_MIN_LONG_PERMILLE 75
 #endif

@@ -337,7 +337,7 @@ def read_bundle_counters() -> Optional[Dict[str, int]]:
     """Synchronising read of `last_bundle_counters` -> which adjoint kernel the last backtrace* call chose, and why.
     The rule is the library's own (`drrt_ring_threshold_pct()`, `drrt_ring_long_threshold_permille()`: its compile-time
     thresholds, so variant builds report what they ran): the ring-window kernel when a fifth of the bundles' START cells do
-    not fit the box window or when 7.5 % of the bundles left the forward march 24 or more iterations apart; its sparse-only
+    not fit the box window or when 7.5 % of the bundles left the forward march 12 or more cells of travel apart (24 iterations at ds = h / 2); its sparse-only
     instantiation unless the call pinned the general one (counter [5])."""
     if last_bundle_counters is None:
         return None

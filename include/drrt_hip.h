@@ -177,8 +177,8 @@ DRRT_API void drrt_set_step_hint(const uint32_t* steps, size_t n);
  *   [0] bundles whose start cells do not fit the box window, [1] bundles looked at,
  *   [2] lanes whose start cell lies more than 3 cells from their bundle's mean cell, [3] lanes looked at (diagnostic),
  *   [4] lanes whose pair partner (lane ^ 1) starts in the same cell (diagnostic), [5] non-zero when the call pinned the
- *   general instantiation of the ring kernel, [6] bundles whose rays' forward iteration counts (step hint) spread over 24 or
- *   more (0 without a hint) (8 ints in all; [7] unused).
+ *   general instantiation of the ring kernel, [6] bundles whose rays' forward iteration counts (step hint) spread over 12
+ *   cells of travel or more (spread * ds / h >= 12: 24 iterations at ds = h / 2; 0 without a hint) (8 ints in all; [7] unused).
  * The ring-window kernel runs when [0] * 100 >= [1] * drrt_ring_threshold_pct() (the library's compile-time threshold, 20 in
  * the product build) or when [6] * 1000 >= [1] * drrt_ring_long_threshold_permille() (75: the box-window kernel does not use
  * the step hint, so rays that left the forward march that far apart run spread along their path beyond its window); its

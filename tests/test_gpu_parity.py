@@ -916,7 +916,7 @@ def test_chunked_adjoint_refuses_inconsistent_calls(gpu, drrt_mod):
 def test_bundle_classification_picks_the_adjoint_kernel(gpu, oracle, drrt_mod):
     """drrt_last_bundle_counters (include/drrt_hip.h; csrc/drrt_march.h: bundles_want_ring / bundles_long /
     bundles_want_sparse): the ring-window kernel when a fifth of the sampled bundles' start cells do not fit the box window
-    OR when 7.5 % of them left the forward march 24 or more iterations apart (counter [6], from the step hint); then its
+    OR when 7.5 % of them left the forward march 12 or more cells of travel apart (24 iterations at ds = h / 2; counter [6], from the step hint); then its
     sparse-only instantiation, unless the call pinned the general one (DRRT_FLAG_RING_GENERAL -> counter [5]).  A sparse
     six-view set goes to the ring kernel; forced either way
     (A-B flags) and chosen by the counters the gradient is the oracle's, and the Python mirror's reading of the counters
@@ -959,6 +959,15 @@ def test_bundle_classification_picks_the_adjoint_kernel(gpu, oracle, drrt_mod):
         c = drrt_mod.read_bundle_counters()
         assert c is not None and c["bundles_long"] == 0, c
         assert cases.rel_l2(g.cpu().numpy(), ob["grad"]) <= 2e-5
+    # the criterion is a LENGTH (iterations * ds / h): the same rays marched at half the step read about the same share
+    pos, vel = cases.cube_rays(2500, span, ds, seed=5, tilt=0.4)
+    share = []
+    for dsx in (ds, ds / 2):
+        xt, vt = T.trace(rif, rif.shape, _t(pos, gpu), _t(vel, gpu), h, dsx)
+        order = drrt_mod.keep_order(drrt_mod.last_order)
+        T.backtrace(rif, rif.shape, xt, vt, torch.ones_like(xt), torch.ones_like(xt), h, dsx, order=order)
+        share.append(drrt_mod.read_bundle_counters()["long_bundle_share"])
+    assert abs(share[0] - share[1]) <= 0.2, share
     # (the dense source at this size: whatever its counters say, asserted above; the metric's plane source at full size
     # stays with the box window: tests/test_baseline_configs.py, tests/test_bench_contract.py)
     assert picked["sparse"] == "ring_sparse", picked
