@@ -169,20 +169,13 @@ static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 // (rocPRIM picks the algorithm by size: up to radix_sort_config<>::merge_sort_limit = 1M items a block sort + merge passes
 // -- 21 launches of 5-9 us for the metric's 1 048 576 rays, 0.167 ms --, Onesweep above.  Lowering the limit so that 1M rays
 // take Onesweep was measured, same box: 0.170 ms at 1M rays, and 0.137 against 0.057 ms for a 131 072-ray shard -- Onesweep's
-// fixed cost is larger than the merge passes'.  The limit stays.)
-// The 32-bit light-field keys: rocPRIM's radix_sort_pairs sorts up to 1M items with a merge sort -- a block sort of 1024 items
-// and 2 launches per doubling, 21 launches of 5-9 us at 1M rays.  A block sort of 512 x 8 = 4096 items leaves 17 launches:
-// 0.167 -> 0.142 ms at 1M rays, 0.058 -> 0.056 at 131 072 (round 4, same box; 512 x 4: 0.162 / 0.050, 512 x 16: 0.150 / 0.060,
-// 256 x 16: 0.145 / 0.058; merge-path items per thread 8 or 16 instead of 4: 0.146 / 0.167).  Above 1M items Onesweep, as before.
-using LfSortConfig = rocprim::radix_sort_config<rocprim::default_config,
-                                                rocprim::merge_sort_config<512, 512, 8, 128, 128, 4>,
-                                                rocprim::default_config, 1024 * 1024>;
+// fixed cost is larger than the merge passes'.  The default stays.)
 static size_t radix_temp_bytes(size_t n) {
   size_t t64 = 0, t32 = 0;          // both key widths share the buffers: the larger temporary storage
   hipError_t e = rocprim::radix_sort_pairs(nullptr, t64, (const uint64_t*)nullptr, (uint64_t*)nullptr,
                                           (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0u, (unsigned)kKeyBits,
                                           (hipStream_t)0);
-  hipError_t e2 = rocprim::radix_sort_pairs<LfSortConfig>(nullptr, t32, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+  hipError_t e2 = rocprim::radix_sort_pairs(nullptr, t32, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                            (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0u, (unsigned)kLfKeyBits,
                                            (hipStream_t)0);
   size_t temp = t64 > t32 ? t64 : t32;
@@ -222,7 +215,7 @@ hipError_t sort_rays_by_entry_voxel(const Vol& V, float h, size_t n, const void*
                        io_half, dir_sign, (uint32_t*)keys_in, idx_in);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs<LfSortConfig>(temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)keys_out,
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)keys_out,
                                   (const uint32_t*)idx_in, idx_out, n, 0u, (unsigned)kLfKeyBits, stream);
   }
   *perm_out = idx_out;
