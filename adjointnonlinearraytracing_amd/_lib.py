@@ -29,7 +29,7 @@ FLAG_STATIC_WINDOW = 0x400000
 FLAG_CHORD_KEY = 0x800000
 FLAG_RING_WINDOW = 0x1000000
 FLAG_DISPATCH_IN_ORDER = 0x2000000
-FLAG_RING_SPARSE, FLAG_RING_GENERAL = 0x4000000, 0x8000000
+FLAG_RING_SPARSE, FLAG_RING_GENERAL, FLAG_RING_DIRECT = 0x4000000, 0x8000000, 0x10000000
 ADAM_MASK_BOUNDARY, ADAM_CLAMP_MIN = 1, 2
 
 ERR_RES_MISMATCH, ERR_BAD_RES, ERR_ARG, ERR_HIP = -1, -2, -3, -4
@@ -98,6 +98,7 @@ SIGNATURES = {
     "drrt_last_bundle_counters": (_vp, []),
     "drrt_ring_threshold_pct": (_i, []),
     "drrt_ring_long_threshold_permille": (_i, []),
+    "drrt_ring_direct_threshold_pct": (_i, []),
     "drrt_profile_begin": (_i, [_i]),
     "drrt_profile_collect": (_i, [_vp, _vp, _i]),
     "drrt_profile_end": (None, []),

@@ -305,13 +305,22 @@ __device__ __forceinline__ int cvt_rpi_i32(float f) {          // floor(f + 0.5)
   asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(i) : "v"(f));
   return i;
 }
-template <bool ABL, bool PAIR, int MODE = 0, bool SPARSE = false>
+// DIRECT (with SPARSE): every STEP's eight contributions go to the window at once -- no per-lane accumulators, no hand-over
+//         on leaving the cell, at the ray's end or at the kernel's: 106 instead of 128 VGPRs, 2530 instead of 2944 static VALU
+//         instructions, one inlined copy of the hand-over instead of four.  8 instead of ~5 LDS adds per lane-step, which is
+//         free where few lanes share a cell (the six views through the weak medium, 2 lanes per cell: 4.84-4.88 -> 4.54-4.59 ms;
+//         through the Luneburg ball, 11 per cell: 6.99-7.21 -> 6.94-7.05) and ruinous where many do (same-address LDS adds
+//         serialise: four views at 4 samples per pixel through the ball, 21 lanes per cell: 6.4 -> 9.0 ms; one view at 45
+//         degrees 6.0 -> 7.6) -- taken per CALL when few pair partners start in the same cell (bundles_want_direct).
+template <bool ABL, bool PAIR, int MODE = 0, bool SPARSE = false, bool DIRECT = false>
 __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : DRRT_RING_WAVES) k_backtrace_ring(BackArgs a) {
+  constexpr bool kDirect = SPARSE && DIRECT;
   constexpr int kRingCap = SPARSE ? DRRT_RING_SPARSE_CAP : DRRT_RING_CAP;
   using WT = typename std::conditional<SPARSE, int, win_t>::type;
   if (a.select != nullptr) {                                 // launched next to k_backtrace_flat: the bundle
     const bool want_fit = bundles_want_ring(a.select);                                // classification picks one of the three
     if (!want_fit || bundles_want_sparse(a.select) != SPARSE) return;
+    if (SPARSE && bundles_want_direct(a.select) != DIRECT) return;
   }
   __shared__ WT s_win[kAdjWavesPerBlock][kRingCap];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
@@ -522,7 +531,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
       }
       if (it >= a.max_steps) {
         if (s.active & (steps >= (unsigned)a.max_steps)) {
-          if (regular && experiment != 1) { if (emit8(lidx, base, sx, sy, sz)) dirty = true; }
+          if (!kDirect && regular && experiment != 1) { if (emit8(lidx, base, sx, sy, sz)) dirty = true; }
           s.active = false;
         }
         // `dirty` guards 64-lane cooperative flushes below: it has to be wave-uniform BEFORE the service of this very
@@ -717,7 +726,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
       AdjSample m;
       if (!adj_sample<MODE>(V, a.sdf, a.ds, s, c, taps_of<PAIR>(q0, q1), m)) {
         // the ray has ended (:426-428): hand over what its cell has accumulated
-        if (regular && experiment != 1) used_lds = emit8(lidx, base, sx, sy, sz);
+        if (!kDirect && regular && experiment != 1) used_lds = emit8(lidx, base, sx, sy, sz);
       } else {
         ++steps;
         const float dn = dot3(s.mx, s.my, s.mz, m.gx, m.gy, m.gz);                            // :430
@@ -726,7 +735,8 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
           const float u = SPARSE ? qs : 1.0f;              // (a power of two: an exact factor of every weight)
           const float ndq = nds * u;
           const CornerPairs cp = splat_weights_pk(wx, wy, wz, (dn * a.ds) * u, ndq * s.mx, ndq * s.my, ndq * s.mz);   // :431-432
-          p00 += cp.c00; p10 += cp.c10; p01 += cp.c01; p11 += cp.c11;
+          if (kDirect) { p00 = cp.c00; p10 = cp.c10; p01 = cp.c01; p11 = cp.c11; used_lds = emit8(lidx, base, sx, sy, sz); }
+          else { p00 += cp.c00; p10 += cp.c10; p01 += cp.c01; p11 += cp.c11; }
         } else if (experiment != 2 && experiment != 1) {
           const Cell cb = locate(V, px, py, pz);
           const Corners w = splat_weights(cb.wx, cb.wy, cb.wz, dn * a.ds, nds * s.mx, nds * s.my, nds * s.mz);
@@ -811,8 +821,10 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
               } else {
                 // out of a cell the window does not hold, into or out of a clamped cell, a jump over more than one cell: all eight
                 if (ABL && dbg) { ++ev_all8; ev_all8g += old_lidx < 0; }
-                if (experiment != 1) used_lds = emit8(old_lidx, old_base, sx, sy, sz);
-                p00 = p10 = p01 = p11 = f2{0.f, 0.f};
+                if (!kDirect) {
+                  if (experiment != 1) used_lds = emit8(old_lidx, old_base, sx, sy, sz);
+                  p00 = p10 = p01 = p11 = f2{0.f, 0.f};
+                }
               }
             }
             if (relocate) {
@@ -839,7 +851,7 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
   STAMP(5)
   STAMP_END
   // rays still marching when max_steps ran out keep what their cell has accumulated: hand it over
-  if (s.active && regular && experiment != 1) { if (emit8(lidx, base, sx, sy, sz)) dirty = true; }
+  if (!kDirect && s.active && regular && experiment != 1) { if (emit8(lidx, base, sx, sy, sz)) dirty = true; }
   dirty = __ballot(dirty) != 0ull;
   if (dirty) { ring_flush<2>(win, R, R.oz, R.nz, a.grad, V, lane, experiment == 2, qinv); ++n_flush; }
   if (ABL && dbg) {
@@ -863,10 +875,18 @@ __global__ void __launch_bounds__(kAdjBlock, SPARSE ? DRRT_RING_SPARSE_WAVES : D
 }
 
 // ---- launcher -----------------------------------------------------------------------------------
-void launch_backtrace_ring_sparse(const BackArgs& a, hipStream_t s) {      // backtrace only (MODE 0)
+// backtrace only (MODE 0).  which: 0 = the accumulating instantiation, 1 = the direct one, 2 = both (classified call: one returns)
+void launch_backtrace_ring_sparse(const BackArgs& a, hipStream_t s, int which) {
   const dim3 g(adj_grid_for(a.n)), b(kAdjBlock);
-  if (a.vol.pair != nullptr) hipLaunchKernelGGL((k_backtrace_ring<false, true, 0, true>), g, b, 0, s, a);
-  else                       hipLaunchKernelGGL((k_backtrace_ring<false, false, 0, true>), g, b, 0, s, a);
+  const bool pair = a.vol.pair != nullptr;
+  if (which != 1) {
+    if (pair) hipLaunchKernelGGL((k_backtrace_ring<false, true, 0, true, false>), g, b, 0, s, a);
+    else      hipLaunchKernelGGL((k_backtrace_ring<false, false, 0, true, false>), g, b, 0, s, a);
+  }
+  if (which != 0) {
+    if (pair) hipLaunchKernelGGL((k_backtrace_ring<false, true, 0, true, true>), g, b, 0, s, a);
+    else      hipLaunchKernelGGL((k_backtrace_ring<false, false, 0, true, true>), g, b, 0, s, a);
+  }
 }
 void launch_backtrace_ring(int mode, bool abl, const BackArgs& a, hipStream_t s) {
   const dim3 g(adj_grid_for(a.n)), b(kAdjBlock);

@@ -64,6 +64,7 @@ static thread_local const unsigned* g_last_counters = nullptr;   // bundle class
 extern "C" const unsigned* drrt_last_bundle_counters(void) { return g_last_counters; }
 extern "C" int drrt_ring_threshold_pct(void) { return DRRT_RING_MIN_NOFIT_PCT; }
 extern "C" int drrt_ring_long_threshold_permille(void) { return DRRT_RING_MIN_LONG_PERMILLE; }
+extern "C" int drrt_ring_direct_threshold_pct(void) { return DRRT_RING_DIRECT_MAX_PAIR_PCT; }
 
 // ---- optional per-kernel timing (bench / profiling aid; not thread-safe) --------------------
 // Event pairs are recorded on the call's stream right around a kernel launch; nothing
@@ -507,11 +508,12 @@ static int run_backtrace(const float* rif, const float* sdf, long long nvox, con
         const bool sparse_ok = MODE == 0 && !abl && !(flags & DRRT_FLAG_RING_GENERAL);
         if (!sparse_ok) { e = hipMemsetAsync((char*)a.select + 20, 1, 1, s); if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(select)"); }
         launch_bundle_classify(a, s);
-        if (sparse_ok) launch_backtrace_ring_sparse(a, s);       // (the classification never picks the general one then)
+        if (sparse_ok) launch_backtrace_ring_sparse(a, s, 2);    // (the classification never picks the general one then)
         else launch_backtrace_ring(MODE, abl, a, s);
       }
       if (!force_ring) launch_backtrace_box(MODE, abl, a, s);
-      if (force_ring && (flags & DRRT_FLAG_RING_SPARSE) && MODE == 0 && !abl) launch_backtrace_ring_sparse(a, s);
+      if (force_ring && (flags & DRRT_FLAG_RING_SPARSE) && MODE == 0 && !abl)
+        launch_backtrace_ring_sparse(a, s, (flags & DRRT_FLAG_RING_DIRECT) ? 1 : 0);
       else if (force_ring) launch_backtrace_ring(MODE, abl, a, s);
     }
   }

@@ -375,6 +375,18 @@ __device__ __forceinline__ bool bundles_want_ring(const unsigned* __restrict__ s
 // their hand-over are gone.  (On compact dense sets -- the metric's -- the general instantiation equals the box window,
 // 4.44 ms, and the sparse-only one takes 5.0: those never come here.)
 __device__ __forceinline__ bool bundles_want_sparse(const unsigned* __restrict__ sel) { return sel[5] == 0u; }
+// ... and of the two sparse-only instantiations the DIRECT one (every step's contributions straight to the window, see
+// k_backtrace_ring) when few lanes share a cell: counter [4] / [3] = share of the sampled lanes whose pair partner starts in
+// the same cell.  Six views through the weak medium 0.31 (2 lanes per cell: direct 6 % faster), through the Luneburg ball 0.56
+// (11 per cell: equal), four views at 4 samples per pixel 0.49 (21 per cell inside the ball: direct 40 % slower).  The start
+// cells say little about a lens set's inside (why this counter could not pick general / sparse-only in the first place), so the
+// threshold sits well below the first set that loses.
+#ifndef DRRT_RING_DIRECT_MAX_PAIR_PCT
+#define DRRT_RING_DIRECT_MAX_PAIR_PCT 40
+#endif
+__device__ __forceinline__ bool bundles_want_direct(const unsigned* __restrict__ sel) {
+  return sel[5] == 0u && sel[3] != 0u && sel[4] * 100u < sel[3] * (unsigned)DRRT_RING_DIRECT_MAX_PAIR_PCT;
+}
 
 // ---------------------------------------------------------------------------------------------
 // cable (radial profile) variants, src/tracer.cpp:312-382 and :511-567
@@ -404,7 +416,7 @@ void launch_backtrace_direct(int mode, const BackArgs& a, hipStream_t s);
 void launch_bundle_classify(const BackArgs& a, hipStream_t s);
 void launch_backtrace_box(int mode, bool abl, const BackArgs& a, hipStream_t s);
 void launch_backtrace_ring(int mode, bool abl, const BackArgs& a, hipStream_t s);
-void launch_backtrace_ring_sparse(const BackArgs& a, hipStream_t s);       // the sparse-only instantiation (backtrace)
+void launch_backtrace_ring_sparse(const BackArgs& a, hipStream_t s, int which);   // the sparse-only instantiations (backtrace)
 // cable (drrt_cable.hip)
 void launch_trace_cable(const CableArgs& a, hipStream_t s);
 void launch_backtrace_cable(const CableArgs& a, hipStream_t s);

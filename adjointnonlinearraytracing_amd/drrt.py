@@ -37,7 +37,7 @@ class Options:
     direct_atomics: bool = False  # adjoint: one global atomic per tap (debug / A-B)
     adjoint_window: str = "auto"  # adjoint: "auto" = the bundles of the call are classified on the device and the box-window kernel
                                   # (k_backtrace_flat) or the ring-window kernel (k_backtrace_ring; its general or its
-                                  # sparse-only instantiation) runs; "box" / "ring" / "ring_sparse" force one, "ring_general"
+                                  # sparse-only instantiations) runs; "box" / "ring" / "ring_sparse" / "ring_direct" force one, "ring_general"
                                   # keeps the choice but never takes the sparse-only instantiation (A-B)
     chord_key: bool = False       # locality sort with the rounds-1/2 key (DRRT_FLAG_CHORD_KEY, A-B)
     pair_grid: object = "auto"    # the "pair copy" of the grid in the workspace (DRRT_FLAG_PAIR_GRID; 8 bytes per voxel, two
@@ -113,6 +113,8 @@ def _flags(adjoint: bool = False) -> int:
         f |= _lib.FLAG_RING_WINDOW
     if adjoint and _opt().adjoint_window == "ring_sparse":       # A-B: the ring kernel's sparse-only instantiation, forced
         f |= _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE
+    if adjoint and _opt().adjoint_window == "ring_direct":       # A-B: ... its direct sparse-only instantiation, forced
+        f |= _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE | _lib.FLAG_RING_DIRECT
     if adjoint and _opt().adjoint_window == "ring_general":      # A-B: device-side choice between box and the GENERAL ring kernel
         f |= _lib.FLAG_RING_GENERAL
     if _opt().chord_key:
@@ -348,11 +350,14 @@ def read_bundle_counters() -> Optional[Dict[str, int]]:
     long_ = bool(c[6] and c[6] * 1000 >= c[1] * ext)
     ring = bool(c[0] and c[0] * 100 >= c[1] * pct) or long_
     sparse = ring and c[5] == 0
+    dpct = int(_lib.load().drrt_ring_direct_threshold_pct())
+    direct = sparse and c[3] != 0 and c[4] * 100 < c[3] * dpct
     return dict(bundles_not_fitting=c[0], bundles=c[1], lanes_outside=c[2], lanes=c[3], not_fitting_share=share,
                 start_pair_share=(c[4] / c[3] if c[3] else 0.0),
                 bundles_long=c[6], long_bundle_share=(c[6] / c[1] if c[1] else 0.0), long_threshold_permille=ext,
                 ring_threshold_pct=pct,
-                kernel=("ring_sparse" if sparse else "ring") if ring else "box")
+                direct_threshold_pct=dpct,
+                kernel=("ring_direct" if direct else "ring_sparse" if sparse else "ring") if ring else "box")
 
 
 def decode_chunk_progress(progress: torch.Tensor) -> Dict[str, object]:

@@ -600,7 +600,10 @@ def run_rank(args) -> int:
                 long_ = bool(c[6] and c[6] * 1000 >= c[1] * ext_min)
                 ring = bool(c[0] and c[0] * 100 >= c[1] * ring_pct) or long_
                 sparse = ring and c[5] == 0
-                choice = {"kernel": ("ring_sparse" if sparse else "ring") if ring else "box",
+                direct_pct = int(lib.drrt_ring_direct_threshold_pct())
+                direct = sparse and c[3] != 0 and c[4] * 100 < c[3] * direct_pct
+                choice = {"kernel": ("ring_direct" if direct else "ring_sparse" if sparse else "ring") if ring else "box",
+                          "start_pair_share": round(c[4] / c[3], 4) if c[3] else None, "direct_max_pair_pct": direct_pct,
                           "bundles_not_fitting": c[0], "bundles_sampled": c[1], "ring_threshold_pct": ring_pct,
                           "lanes_far_from_bundle": c[2], "lanes_sampled": c[3],
                           "long_bundle_share": round(c[6] / c[1], 4) if c[1] else None, "ring_min_long_permille": ext_min}

@@ -86,6 +86,8 @@ extern "C" {
 #define DRRT_FLAG_RING_SPARSE  0x4000000u  /* with RING_WINDOW (A-B): the sparse-only instantiation of the ring-window kernel (every cell
                                               leave hands over all eight corners; chosen by itself for sparse ray sets) */
 #define DRRT_FLAG_RING_GENERAL 0x8000000u  /* backtrace (A-B): never the sparse-only instantiation (the per-wave dense / sparse rule only) */
+#define DRRT_FLAG_RING_DIRECT  0x10000000u /* with RING_WINDOW | RING_SPARSE (A-B): the DIRECT sparse-only instantiation (every step's eight
+                                              contributions straight to the window; chosen by itself when few lanes share a cell) */
 #define DRRT_FLAG_STATIC_WINDOW 0x400000u  /* backtrace, backtrace_sdf: always the box-window kernel (k_backtrace_flat, compile-time 9^3 gradient
                                               windows), no per-call bundle classification */
 #define DRRT_FLAG_DISPATCH_IN_ORDER 0x2000000u /* trace, trace_pln, backtrace, backtrace_sdf (A-B measurement; forward bit-identical, adjoint the same
@@ -182,12 +184,15 @@ DRRT_API void drrt_set_step_hint(const uint32_t* steps, size_t n);
  * The ring-window kernel runs when [0] * 100 >= [1] * drrt_ring_threshold_pct() (the library's compile-time threshold, 20 in
  * the product build) or when [6] * 1000 >= [1] * drrt_ring_long_threshold_permille() (75: the box-window kernel does not use
  * the step hint, so rays that left the forward march that far apart run spread along their path beyond its window); its
- * sparse-only instantiation (fixed-point window) unless [5] is set.  Calibration:
+ * sparse-only instantiation (fixed-point window) unless [5] is set -- the one that hands over per step ("direct") when
+ * [4] * 100 < [3] * drrt_ring_direct_threshold_pct() (40: few lanes share a cell), else the one that hands over per cell.
+ * Calibration:
  * csrc/drrt_march.h, bundles_want_ring / bundles_long / bundles_want_sparse.  The counters describe the START cells of the
  * bundles (the exit rays as given), not where the step hint's delays put the lanes later on. */
 DRRT_API const unsigned* drrt_last_bundle_counters(void);
 DRRT_API int drrt_ring_threshold_pct(void);
 DRRT_API int drrt_ring_long_threshold_permille(void);   /* ring kernel also when counters [6] * 1000 >= [1] * this */
+DRRT_API int drrt_ring_direct_threshold_pct(void);      /* its direct sparse-only instantiation when counters [4] * 100 < [3] * this */
 
 /* ---- 16-bit ray state "q16" (BASELINE.json config 5: "fp16 ray state + fp32 adjoint accumulate") -----------------
  * The reference is fp32-only (include/types.h:36-46).  IEEE half keeps 11 significant bits wherever the value is:

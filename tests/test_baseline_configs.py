@@ -537,3 +537,5 @@ def test_bench_workloads_against_the_oracle_at_full_size(gpu, oracle, D, workloa
     assert c is not None
     if workload != "tomo_weak":           # (the weak medium's straight rays sit between the two regimes: either kernel is right)
         assert c["kernel"] == ("box" if workload == "metric" else "ring_sparse"), c      # ~2 rays per cell column: sparse-only
+    else:
+        assert c["kernel"] in ("ring_sparse", "ring_direct"), c

@@ -83,14 +83,15 @@ def test_fuzz_against_oracle(gpu, oracle, seed):
                 gr2 = T.backtrace(R, res, P, V, _t(c["dx"], gpu), _t(c["dv"], gpu), h, ds)
                 assert drrt.read_stats()["ray_steps"] == obr["steps_total"]
                 assert cases.grads_agree(gr2.cpu().numpy(), obr["grad"])
-            # ---- ... and on its sparse-only instantiation (32-bit fixed-point window: the one a classified call takes)
-            with drrt.using(adjoint_window="ring_sparse"):
-                g3 = T.backtrace(R, res, xt, vt, _t(c["dx"], gpu), _t(c["dv"], gpu), h, ds, order=order)
-                assert drrt.read_stats()["ray_steps"] == ob["steps_total"]
-                assert cases.rel_l2(g3.cpu().numpy(), ob["grad"]) <= 2e-5 or scale < 1e-20
-                gr3 = T.backtrace(R, res, P, V, _t(c["dx"], gpu), _t(c["dv"], gpu), h, ds)
-                assert drrt.read_stats()["ray_steps"] == obr["steps_total"]
-                assert cases.grads_agree(gr3.cpu().numpy(), obr["grad"])
+            # ---- ... and on its two sparse-only instantiations (32-bit fixed-point window: what a classified call takes)
+            for mode in ("ring_sparse", "ring_direct"):
+                with drrt.using(adjoint_window=mode):
+                    g3 = T.backtrace(R, res, xt, vt, _t(c["dx"], gpu), _t(c["dv"], gpu), h, ds, order=order)
+                    assert drrt.read_stats()["ray_steps"] == ob["steps_total"]
+                    assert cases.rel_l2(g3.cpu().numpy(), ob["grad"]) <= 2e-5 or scale < 1e-20, mode
+                    gr3 = T.backtrace(R, res, P, V, _t(c["dx"], gpu), _t(c["dv"], gpu), h, ds)
+                    assert drrt.read_stats()["ray_steps"] == obr["steps_total"]
+                    assert cases.grads_agree(gr3.cpu().numpy(), obr["grad"]), mode
     finally:
         drrt.options.sort_rays = True
         drrt.options.quad_grid = False

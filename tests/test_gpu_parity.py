@@ -754,6 +754,7 @@ def test_adjoint_kernel_variants_agree(gpu, oracle, drrt_mod, kind, R, step_res)
     assert drrt_mod.last_order is not None and fsteps is not None and fsteps.numel() == n
     variants = [("flat", _lib.FLAG_STATIC_WINDOW), ("auto", 0), ("ring", _lib.FLAG_RING_WINDOW),
                 ("ring_sparse", _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE),
+                ("ring_direct", _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE | _lib.FLAG_RING_DIRECT),
                 ("ring_chord", _lib.FLAG_RING_WINDOW | _lib.FLAG_CHORD_KEY), ("flat_chord", _lib.FLAG_STATIC_WINDOW | _lib.FLAG_CHORD_KEY),
                 ("direct", _lib.FLAG_DIRECT_ATOMICS)]
     for name, fl in variants:
@@ -816,6 +817,8 @@ def test_ring_window_with_rays_that_run_out_of_steps_beside_delayed_lanes(gpu, o
     for name, fl, hint in (("ring+steps", _lib.FLAG_RING_WINDOW, True), ("ring", _lib.FLAG_RING_WINDOW, False),
                            ("ring_sparse+steps", _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE, True),
                            ("ring_sparse", _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE, False),
+                           ("ring_direct+steps", _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE | _lib.FLAG_RING_DIRECT, True),
+                           ("ring_direct", _lib.FLAG_RING_WINDOW | _lib.FLAG_RING_SPARSE | _lib.FLAG_RING_DIRECT, False),
                            ("box", _lib.FLAG_STATIC_WINDOW, False), ("direct", _lib.FLAG_DIRECT_ATOMICS, False)):
         flags = fl | _lib.FLAG_SORT_RAYS
         ws = torch.empty(int(lib.drrt_workspace_bytes_grid(n, rif.numel(), flags)) + 1024, dtype=torch.uint8, device=gpu)
@@ -830,7 +833,7 @@ def test_ring_window_with_rays_that_run_out_of_steps_beside_delayed_lanes(gpu, o
         assert int(st[0]) == ob["steps_total"], name
         grads[name] = g.cpu().numpy()
         assert cases.rel_l2(grads[name], ob["grad"]) <= 2e-5, name
-    for name in ("ring+steps", "ring", "ring_sparse+steps", "ring_sparse", "box"):
+    for name in ("ring+steps", "ring", "ring_sparse+steps", "ring_sparse", "ring_direct+steps", "ring_direct", "box"):
         assert cases.rel_l2(grads[name], grads["direct"]) <= 2e-5, name
 
 
@@ -937,7 +940,7 @@ def test_bundle_classification_picks_the_adjoint_kernel(gpu, oracle, drrt_mod):
         with oracle.arith("factored"):
             ob = oracle.backtrace(rif_np, rif_np.shape, xt.cpu().numpy(), vt.cpu().numpy(), np.ones_like(pos), np.ones_like(pos),
                                   h, ds, dtype=np.float32)
-        for mode in ("auto", "ring", "ring_sparse", "ring_general", "box"):
+        for mode in ("auto", "ring", "ring_sparse", "ring_direct", "ring_general", "box"):
             with drrt_mod.using(adjoint_window=mode):
                 g = T.backtrace(rif, rif.shape, xt, vt, ones, ones, h, ds, order=order)
                 c = drrt_mod.read_bundle_counters()
@@ -947,7 +950,8 @@ def test_bundle_classification_picks_the_adjoint_kernel(gpu, oracle, drrt_mod):
                 assert c is not None and c["bundles"] > 0
                 long_ = c["bundles_long"] > 0 and c["bundles_long"] * 1000 >= c["bundles"] * c["long_threshold_permille"]
                 nofit = c["bundles_not_fitting"] > 0 and c["bundles_not_fitting"] * 100 >= c["bundles"] * c["ring_threshold_pct"]
-                assert c["kernel"] == ("ring_sparse" if (long_ or nofit) else "box"), (name, c)
+                few = c["lanes"] > 0 and c["start_pair_share"] * 100 < c["direct_threshold_pct"]
+                assert c["kernel"] == (("ring_direct" if few else "ring_sparse") if (long_ or nofit) else "box"), (name, c)
                 picked[name] = c["kernel"]
             elif mode == "ring_general":                          # classifies, but never the sparse-only instantiation
                 assert c is not None and c["kernel"] in ("box", "ring"), (name, c)
@@ -970,7 +974,7 @@ def test_bundle_classification_picks_the_adjoint_kernel(gpu, oracle, drrt_mod):
     assert abs(share[0] - share[1]) <= 0.2, share
     # (the dense source at this size: whatever its counters say, asserted above; the metric's plane source at full size
     # stays with the box window: tests/test_baseline_configs.py, tests/test_bench_contract.py)
-    assert picked["sparse"] == "ring_sparse", picked
+    assert picked["sparse"] in ("ring_sparse", "ring_direct"), picked
 
 
 @pytest.mark.parametrize("case", ["wide_range", "growing", "zero_seeds", "one_nan"])
@@ -1007,26 +1011,29 @@ def test_fixed_point_window_of_the_sparse_ring_kernel(gpu, oracle, drrt_mod, cas
     with oracle.arith("factored"):
         ob = oracle.backtrace(rif_np, rif_np.shape, xt_n, vt_n, dx, dv, h, ds, dtype=np.float32)
     grads = {}
-    for mode in ("ring_sparse", "ring"):
+    for mode in ("ring_sparse", "ring_direct", "ring"):
         with drrt_mod.using(adjoint_window=mode):
             grads[mode] = T.backtrace(rif, rif.shape, xt, vt, _t(dx, gpu), _t(dv, gpu), h, ds, order=order).cpu().numpy()
         assert drrt_mod.read_stats()["ray_steps"] == ob["steps_total"], mode
     ref = ob["grad"]
     if case == "zero_seeds":
-        assert not grads["ring_sparse"].any() and not grads["ring"].any()
+        assert not grads["ring_sparse"].any() and not grads["ring_direct"].any() and not grads["ring"].any()
         return
     if case == "one_nan":
         ok = np.isfinite(ref)
         assert (~ok).any() and np.array_equal(np.isfinite(grads["ring_sparse"]), ok)
+        assert np.array_equal(np.isfinite(grads["ring_direct"]), ok)
         with oracle.arith("factored"):            # the same march without that ray: the finite voxels must agree with it
             keep = np.arange(n) != n // 2
             ob2 = oracle.backtrace(rif_np, rif_np.shape, xt_n[keep], vt_n[keep], dx[keep], dv[keep], h, ds, dtype=np.float32)
         assert cases.rel_l2(grads["ring_sparse"][ok], ob2["grad"][ok]) <= 2e-5
+        assert cases.rel_l2(grads["ring_direct"][ok], ob2["grad"][ok]) <= 2e-5
         return
-    for mode in ("ring_sparse", "ring"):
+    for mode in ("ring_sparse", "ring_direct", "ring"):
         assert cases.rel_l2(grads[mode], ref) <= 2e-5, (case, mode, cases.rel_l2(grads[mode], ref))
-    err = np.abs(grads["ring_sparse"].astype(np.float64) - ref)
-    assert err.max() <= 2e-4 * np.abs(ref).max(), (case, err.max(), np.abs(ref).max())
+    for mode in ("ring_sparse", "ring_direct"):
+        err = np.abs(grads[mode].astype(np.float64) - ref)
+        assert err.max() <= 2e-4 * np.abs(ref).max(), (case, mode, err.max(), np.abs(ref).max())
 
 
 def test_q16_ray_state_mode(gpu, drrt_mod):

@@ -39,7 +39,7 @@ def probe(name, n, xs, vs):
     out = {"case": name}
     v = vt.abs()
     out["minor_over_major"] = round(float((v.sort(dim=1).values[:, 1] / v.max(dim=1).values).mean()), 3)
-    for mode in ("auto", "box", "ring_general", "ring_sparse"):
+    for mode in ("auto", "box", "ring_general", "ring_sparse", "ring_direct"):
         with drrt.using(adjoint_window=mode):
             ta = timeit(lambda: T.backtrace(n, res, xt, vt, ones, ones, h, ds, order=order))
             c = drrt.read_bundle_counters()
@@ -48,7 +48,7 @@ def probe(name, n, xs, vs):
             out["auto_kernel"] = c["kernel"]
             out["not_fitting"], out["long_share"] = round(c["not_fitting_share"], 3), round(c["long_bundle_share"], 3)
     ns = drrt.read_stats()["ray_steps"]
-    out["best"] = min(("box", "ring_general", "ring_sparse"), key=lambda m: out[m])
+    out["best"] = min(("box", "ring_general", "ring_sparse", "ring_direct"), key=lambda m: out[m])
     out["ray_steps"] = ns
     print(json.dumps(out), flush=True)
 

@@ -54,7 +54,7 @@ def probe(name, n, xs, vs, force=None):
         v = vt[o].abs()
         out["mean_minor_over_major"] = round(float((v.sort(dim=1).values[:, 1] / v.max(dim=1).values).mean()), 2)
         out["mean_least_over_major"] = round(float((v.min(dim=1).values / v.max(dim=1).values).mean()), 2)
-    for mode in ([force] if force else ["auto", "ring_general", "ring_sparse", "box"]):
+    for mode in ([force] if force else ["auto", "ring_general", "ring_sparse", "ring_direct", "box"]):
         with drrt.using(adjoint_window=mode):
             ta = timeit(lambda: T.backtrace(n, res, xt, vt, ones, ones, h, ds, order=order))
             c = drrt.read_bundle_counters()
